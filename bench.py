@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Headline benchmark: stereo STFT frames/s through the whole GCC-NMF hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, config 2 parameters on config 3's batch): every rank owns `--files`
+(default 64) synthetic 10 s stereo mixtures @16 kHz (SURVEY.md 8d recipe), 1024-pt FFT, hop 256,
+K = 1024 atoms, 100 KL-NMF iterations, 128 TDOAs, 3 targets.  One step = one pass of the hot path over
+the rank's batch: samples already resident in HBM -> STFT -> KL-NMF -> GCC-PHAT localisation ->
+GCC-NMF masks -> reconstruction -> iSTFT/OLA -> separated waveforms in HBM.  Files are independent,
+so ranks share nothing on the data path (weak scaling, no collective inside the timed region).
+
+Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel live with HIP events on the
+launch stream; `cpu_baseline` times the NumPy oracle (a port of the reference) on one file.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--files', type=int, default=64, help='mixture files per GPU per step')
+    p.add_argument('--dictionary-size', type=int, default=1024)
+    p.add_argument('--iterations', type=int, default=100)
+    p.add_argument('--hop', type=int, default=256)
+    p.add_argument('--seconds', type=float, default=10.0)
+    p.add_argument('--no-xcd-affinity', action='store_true')
+    p.add_argument('--skip-roofline', action='store_true')
+    p.add_argument('--skip-cpu-baseline', action='store_true')
+    return p.parse_args()
+
+
+def kernel_timings(e, reps):
+    """Average duration of each of the five per-iteration launches, measured with HIP events recorded on
+    the stream the kernels are launched on (torch's current stream), inside real iterations."""
+    import torch
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.engine import _ptr, _stream
+    g, lib = e.g, e.lib
+    e.W.copy_(e.W0.unsqueeze(0).expand_as(e.W))
+    e.H.copy_(e.H0.unsqueeze(0).expand_as(e.H))
+
+    def stage(s):
+        _hip.check(lib.gccnmf_klnmf_stage(_ptr(e.V), _ptr(e.W), _ptr(e.H), _ptr(e.ws_nmf), g.F, g.N, g.K, e.batch, e.alpha,
+                                          e.eps, e.klnmf_flags, s, _stream()), 'gccnmf_klnmf_stage')
+    stage(0)
+    for s in range(1, 6):
+        stage(s)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
+    torch.cuda.synchronize()
+    for r in range(reps):
+        ev[r][0].record()
+        for s in range(1, 6):
+            stage(s)
+            ev[r][s].record()
+    torch.cuda.synchronize()
+    ms = np.array([[ev[r][s - 1].elapsed_time(ev[r][s]) for s in range(1, 6)] for r in range(reps)])
+    return ms.mean(axis=0)
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    from gcc_nmf_amd.synthetic import synthetic_batch
+
+    sr = 16000
+    n = int(a.seconds * sr)
+    K, iters, B = a.dictionary_size, a.iterations, a.files
+    xs = synthetic_batch(rank * B, B, numSamples=n, sampleRate=sr)          # each rank: its own shard of files
+    e = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=a.hop, numTDOAs=128, microphoneSeparationInMetres=1.0,
+                     numTargets=3, dictionarySize=K, numIterations=iters, batch=B, device='cuda:%d' % local_rank,
+                     klnmf_flags=1 if a.no_xcd_affinity else 0)
+    g = e.g
+    e.upload(xs)                                                             # inputs resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for _ in range(a.warmup):
+        e.run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        e.run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    e.check_status()
+    idx_ok = bool((e.get_tdoa_indexes() == np.array([27, 59, 91])).all()) if a.seconds == 10.0 else None
+
+    frames = world * B * g.T * a.steps
+    out = {
+        'metric': 'stereo frames/sec (1024-FFT, K=%d, %d NMF iters)' % (K, iters),
+        'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%d x %.0f s stereo @16 kHz synthetic mixtures per GPU (SURVEY 8d recipe), 1024-pt FFT hop %d '
+                               '(F=513, T=%d/file), K=%d, %d KL-NMF iters, 128 TDOAs, 3 targets; end-to-end samples-in-HBM -> '
+                               'separated waveforms-in-HBM, independent dictionary per file' % (B, a.seconds, a.hop, g.T, K, iters),
+                   'files_per_gpu': B, 'frames_per_file': g.T, 'dictionary_size': K, 'nmf_iterations': iters,
+                   'parallelism': 'file-sharded x%d, no data-path collective' % world},
+        'tdoa_indexes_as_expected': idx_ok,
+    }
+
+    if rank == 0 and not a.skip_roofline:
+        ms = kernel_timings(e, reps=5)
+        flop_per_launch = 2.0 * g.F * g.K * g.N * B                          # algorithmic: F=513, N=2T, not the padded tile grid
+        names = ['K1 R=V/(W.(s*H))', 'K2 H*=W^T.R/colsum', 'K3 R=V/(W.H)', 'K4a U=R.H^T', 'K4b W update+normalise']
+        kern = {}
+        for i, nm in enumerate(names):
+            kern[nm] = {'avg_ms': float(ms[i])}
+            if i < 4:
+                kern[nm]['tflops'] = flop_per_launch / (ms[i] * 1e-3) / 1e12
+        achieved = flop_per_launch / (ms[0] * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_kernel<4,1,A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
+                           'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+                           'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(ms[0])}
+        out['kernels'] = kern
+        out['nmf_iteration_ms'] = float(ms.sum())
+        out['nmf_gemm_tflops_per_iteration'] = 4 * flop_per_launch / (ms.sum() * 1e-3) / 1e12
+
+    if rank == 0 and world == 1 and not a.skip_cpu_baseline:
+        from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count()
+        t1 = time.perf_counter()
+        r = O.runGCCNMF(xs[0], sr, 1024, a.hop, 128, 1.0, 3, dictionarySize=K, numIterations=iters, return_intermediates=True)
+        dt = time.perf_counter() - t1
+        out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
+                               'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle '
+                                         '(oracle/gccnmf_oracle.py), %.1f s' % (B, g.T, dt),
+                               'host_cpus': os.cpu_count()}
+        y0 = e.y[0].cpu().numpy()
+        out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))
+        out['gpu_vs_cpu_tdoa_equal'] = bool(e.get_tdoa_indexes()[0].tolist() == r['idx'])
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

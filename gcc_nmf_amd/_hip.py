@@ -1,0 +1,88 @@
+"""ctypes binding of libgccnmf_hip.so (include/gccnmf_hip.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is
+missing (or its symbols do not match the header) importing this module's
+``lib()`` raises ``HipLibraryError`` -- loudly, on every call path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgccnmf_hip.so')
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+P_INT = ctypes.POINTER(ctypes.c_int)
+
+STATUS = {0: 'GCCNMF_OK', 1: 'GCCNMF_ERR_ARG (bad argument)', 2: 'GCCNMF_ERR_LAUNCH (HIP launch failed)',
+          3: 'GCCNMF_ERR_UNSUPPORTED'}
+
+# name -> (restype, argtypes); mirrors include/gccnmf_hip.h declaration by declaration
+SIGNATURES = {
+    'gccnmf_version': (c_int, []),
+    'gccnmf_pitches': (c_int, [c_int, c_int, c_int, P_INT, P_INT, P_INT, P_INT]),
+    'gccnmf_stft_stereo': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_klnmf_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
+    'gccnmf_klnmf': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                             c_float, c_int, c_void_p]),
+    'gccnmf_klnmf_stage': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                   c_int, c_int, c_void_p]),
+    'gccnmf_klnmf_shared_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
+    'gccnmf_klnmf_shared_partial_floats': (c_long, [c_int, c_int]),
+    'gccnmf_klnmf_shared_begin': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'gccnmf_klnmf_shared_step_a': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_float, c_float, c_void_p]),
+    'gccnmf_klnmf_shared_step_b': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'gccnmf_klnmf_shared_finish': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'gccnmf_angular_spectrogram': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p]),
+    'gccnmf_pick_tdoa_peaks': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_scores_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
+    'gccnmf_target_scores_masks': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_argmax_targets': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'gccnmf_coherence': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'gccnmf_reconstruct_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
+    'gccnmf_reconstruct': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_istft_ola': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    'gccnmf_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library with typed prototypes; raises HipLibraryError if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C gcc_nmf_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise HipLibraryError('%s does not export %s (stale build? re-run make -C gcc_nmf_amd/csrc)' % (LIB_PATH, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise HipLibraryError('%s failed: %s' % (what, STATUS.get(status, 'status %d' % status)))

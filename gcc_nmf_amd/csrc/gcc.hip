@@ -1,0 +1,272 @@
+// GCC-PHAT localisation, GCC-NMF target scores / coefficient masks and masked reconstruction.
+// Reference: gccNMF/gccNMFFunctions.py:85-151 and gccNMF/runGCCNMF.py:46.
+//
+// Every contraction here is a real GEMM on the f32 matrix cores (gemm_mfma.h):
+//   angular spectrogram   A[tau,t]  = [cos;sin]^T (D x 2Fp) . [Re C; Im C] (2Fp x T)        (:88-92)
+//   GCC-NMF scores        G_i[k,t]  = W^T (K x F) . P_i (F x T),  P_i = Re(C * exp(-j w tau_i))  (:127-133)
+//   reconstruction        S[i,c]    = W (F x K) . (H_c * M_i) (K x T)  * X_c/|X_c|           (:147-151)
+// The three targets / six (target, channel) pairs are concatenated along the GEMM's column axis,
+// so each stage is ONE launch for the whole batch.
+#include "gemm_mfma.h"
+
+// mean over time of the angular spectrogram, accumulated in double (runGCCNMF.py:46 works on float64).
+// grid = batch * D, 256 threads.
+__global__ __launch_bounds__(256) void ang_mean_kernel(const float* __restrict__ ang, int T, int D, int Dp, int Tp,
+                                                       double* __restrict__ mean_ang) {
+    __shared__ double red[256];
+    const int b = blockIdx.x / D, d = blockIdx.x - b * D;
+    const float* row = ang + ((long)b * Dp + d) * Tp;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) s += (double)row[t];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean_ang[(long)b * Dp + d] = red[0] / (double)T;
+}
+
+// Strict local maxima (scipy.signal.argrelmax, order 1: edges never qualify, NaN never compares greater),
+// keep the S largest, ascending index order.  One 64-thread block per file; D <= 4096.
+__global__ __launch_bounds__(64) void pick_peaks_kernel(const double* __restrict__ mean_ang, int D, int Dp, int S,
+                                                        int* __restrict__ tdoa_idx, int* __restrict__ status) {
+    __shared__ double v[4096];
+    __shared__ unsigned char is_peak[4096];
+    const int b = blockIdx.x;
+    const double* m = mean_ang + (long)b * Dp;
+    for (int i = threadIdx.x; i < D; i += 64) v[i] = m[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 64) is_peak[i] = (i > 0 && i < D - 1 && v[i] > v[i - 1] && v[i] > v[i + 1]) ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int found = 0;
+        int* out = tdoa_idx + (long)b * S;
+        for (int s = 0; s < S; ++s) {
+            int best = -1;
+            for (int i = 1; i < D - 1; ++i)
+                if (is_peak[i] == 1 && (best < 0 || v[i] > v[best])) best = i;
+            if (best < 0) break;
+            is_peak[best] = 2;
+            ++found;
+        }
+        int n = 0;
+        for (int i = 1; i < D - 1 && n < S; ++i)
+            if (is_peak[i] == 2) out[n++] = i;
+        for (; n < S; ++n) out[n] = -1;
+        status[b] = (found == S) ? 0 : 1;
+    }
+}
+
+// P[f][i*Tp + t] = Re(C[f,t] * exp(-j 2 pi f tau_i)) = Cr*cos + Ci*sin, zero in every padded position.
+// grid = (ceil(S*Tp/256), Fp, batch)
+__global__ __launch_bounds__(256) void gcc_steer_kernel(const float* __restrict__ CC, const float* __restrict__ trig,
+                                                        const int* __restrict__ tdoa_idx, int F, int Fp, int T, int Tp, int D,
+                                                        int Dp, int S, float* __restrict__ P) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z;
+    if (col >= S * Tp) return;
+    const int i = col / Tp, t = col - i * Tp;
+    float out = 0.f;
+    if (f < F && t < T) {
+        int tau = tdoa_idx[(long)b * S + i];
+        tau = tau < 0 ? 0 : (tau >= D ? D - 1 : tau);
+        const long plane = (long)Fp * Tp;
+        const float cr = CC[(long)b * 2 * plane + (long)f * Tp + t];
+        const float ci = CC[(long)b * 2 * plane + plane + (long)f * Tp + t];
+        const float c = trig[(long)f * Dp + tau], s = trig[((long)Fp + f) * Dp + tau];
+        out = cr * c + ci * s;
+    }
+    P[((long)b * Fp + f) * ((long)S * Tp) + col] = out;
+}
+
+// argmax over targets, first index wins ties, NaN ignored (numpy.nanargmax, gccNMFFunctions.py:138).
+// grid = (ceil(Tp/256), Kp, batch)
+__global__ __launch_bounds__(256) void gcc_argmax_kernel(const float* __restrict__ scores, int K, int Kp, int T, int Tp, int S,
+                                                         unsigned char* __restrict__ argmax) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    if (t >= Tp) return;
+    unsigned char best = 0;
+    if (k < K && t < T) {
+        const float* row = scores + ((long)b * Kp + k) * ((long)S * Tp) + t;
+        float bv = 0.f;
+        bool have = false;
+        for (int i = 0; i < S; ++i) {
+            const float v = row[(long)i * Tp];
+            if (v != v) continue;
+            if (!have || v > bv) {
+                bv = v;
+                best = (unsigned char)i;
+                have = true;
+            }
+        }
+    }
+    argmax[((long)b * Kp + k) * Tp + t] = best;
+}
+
+// PHAT coherence X0*conj(X1)/|X0|/|X1| from an existing spectrogram (runGCCNMF.py:44); the pipeline gets
+// it for free from the STFT epilogue, this standalone form serves the host-array API.
+// grid = (ceil(T/256), F, batch)
+__global__ __launch_bounds__(256) void gcc_coherence_kernel(const float2* __restrict__ X, int Fp, int T, int Tp,
+                                                            float* __restrict__ CC) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long plane = (long)Fp * Tp;
+    const float2 xl = X[(long)b * 2 * plane + (long)f * Tp + t];
+    const float2 xr = X[(long)b * 2 * plane + plane + (long)f * Tp + t];
+    const float aL = hypotf(xl.x, xl.y), aR = hypotf(xr.x, xr.y);
+    float re = xl.x * xr.x + xl.y * xr.y, im = xl.y * xr.x - xl.x * xr.y;
+    re = re / aL / aR;
+    im = im / aL / aR;
+    float* Cb = CC + (long)b * 2 * plane + (long)f * Tp + t;
+    Cb[0] = re;
+    Cb[plane] = im;
+}
+
+// Hm[k][(i*2+c)*Tp + t] = H[k][c*T + t] if argmax[k][t] == i else 0 (H_c * M_i, gccNMFFunctions.py:150).
+// grid = (ceil(2*S*Tp/256), Kp, batch)
+__global__ __launch_bounds__(256) void gcc_masked_h_kernel(const float* __restrict__ H, const unsigned char* __restrict__ argmax,
+                                                           const float* __restrict__ masks, int K, int Kp, int T, int Tp, int Np,
+                                                           int S, float* __restrict__ Hm) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int ncol = 2 * S * Tp;
+    if (col >= ncol) return;
+    const int ic = col / Tp, t = col - ic * Tp;
+    const int i = ic >> 1, c = ic & 1;
+    float out = 0.f;
+    if (k < K && t < T) {
+        const float h = H[((long)b * Kp + k) * Np + c * T + t];
+        if (masks)   // arbitrary (soft) masks [batch][S][Kp][Tp]: coefficients * targetCoefficientMask
+            out = h * masks[(((long)b * S + i) * Kp + k) * Tp + t];
+        else if (argmax[((long)b * Kp + k) * Tp + t] == i)
+            out = h;
+    }
+    Hm[((long)b * Kp + k) * (long)ncol + col] = out;
+}
+
+extern "C" {
+
+int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T, int D, int batch, float* ang,
+                               double* mean_ang, void* stream) {
+    if (!CC || !trig || !ang || F < 2 || T < 1 || D < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    const int Dp = gccnmf_round_up(D, 64);
+    GemmArgs a = {};
+    a.A = trig; a.sA = 0; a.lda = Dp; a.a_clamp = Dp - 4;
+    a.B = CC; a.sB = 2L * p.Fp * p.Tp; a.ldb = p.Tp; a.b_clamp = p.Tp - 4;
+    a.M = D; a.N = T; a.Kd = 2 * p.Fp;
+    a.batch = batch; a.xcd_affine = 0;
+    a.C = ang; a.sC = (long)Dp * p.Tp; a.ldc = p.Tp;
+    int rc = (D > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
+                       : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
+    if (rc) return rc;
+    if (mean_ang) {
+        hipLaunchKernelGGL(ang_mean_kernel, dim3(batch * D), dim3(256), 0, s, ang, T, D, Dp, p.Tp, mean_ang);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    return GCCNMF_OK;
+}
+
+int gccnmf_pick_tdoa_peaks(const double* mean_ang, int D, int Dp, int S, int batch, int* tdoa_idx, int* status,
+                           void* stream) {
+    if (!mean_ang || !tdoa_idx || !status || D < 3 || D > 4096 || Dp < D || S < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipLaunchKernelGGL(pick_peaks_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, mean_ang, D, Dp, S, tdoa_idx, status);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+long gccnmf_scores_workspace_floats(int F, int T, int S, int batch) {
+    if (F < 2 || T < 1 || S < 1 || batch < 1) return -1;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    return (long)batch * p.Fp * S * p.Tp;
+}
+
+int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* tdoa_idx, const float* W, int F, int T,
+                               int K, int D, int S, int batch, float* workspace, float* scores, unsigned char* argmax,
+                               void* stream) {
+    if (!CC || !trig || !tdoa_idx || !W || !workspace || !scores || F < 2 || T < 1 || K < 1 || D < 1 || S < 1 || S > 255 ||
+        batch < 1)
+        return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, K);
+    const int Dp = gccnmf_round_up(D, 64);
+    const int ncol = S * p.Tp;
+    float* P = workspace;
+    hipLaunchKernelGGL(gcc_steer_kernel, dim3(gccnmf_ceil_div(ncol, 256), p.Fp, batch), dim3(256), 0, s, CC, trig, tdoa_idx, F,
+                       p.Fp, T, p.Tp, D, Dp, S, P);
+    GCCNMF_CHECK_LAUNCH();
+    GemmArgs a = {};
+    a.A = W; a.sA = (long)p.Fp * p.Kp; a.lda = p.Kp; a.a_clamp = p.Kp - 4;
+    a.B = P; a.sB = (long)p.Fp * ncol; a.ldb = ncol; a.b_clamp = ncol - 4;
+    a.M = K; a.N = ncol; a.Kd = F;
+    a.batch = batch; a.xcd_affine = 1;
+    a.C = scores; a.sC = (long)p.Kp * ncol; a.ldc = ncol;
+    int rc = (K > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
+                       : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
+    if (rc) return rc;
+    if (argmax) {
+        hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 256), p.Kp, batch), dim3(256), 0, s, scores, K, p.Kp, T,
+                           p.Tp, S, argmax);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    return GCCNMF_OK;
+}
+
+int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, unsigned char* argmax, void* stream) {
+    if (!scores || !argmax || K < 1 || T < 1 || S < 1 || S > 255 || batch < 1) return GCCNMF_ERR_ARG;
+    GccNmfPitches p = gccnmf_make_pitches(2, T, K);
+    hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 256), p.Kp, batch), dim3(256), 0, (hipStream_t)stream, scores,
+                       K, p.Kp, T, p.Tp, S, argmax);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* stream) {
+    if (!X || !CC || F < 2 || T < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    hipLaunchKernelGGL(gcc_coherence_kernel, dim3(gccnmf_ceil_div(T, 256), F, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)X, p.Fp, T, p.Tp, CC);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+long gccnmf_reconstruct_workspace_floats(int T, int K, int S, int batch) {
+    if (T < 1 || K < 1 || S < 1 || batch < 1) return -1;
+    GccNmfPitches p = gccnmf_make_pitches(2, T, K);
+    return (long)batch * p.Kp * 2 * S * p.Tp;
+}
+
+int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argmax, const float* masks, const float* X,
+                       const float* V, int F, int T, int K, int S, int batch, float* workspace, float* spec, void* stream) {
+    if (!W || !H || (!argmax && !masks) || !X || !V || !workspace || !spec || F < 2 || T < 1 || K < 1 || S < 1 || batch < 1)
+        return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, K);
+    const int ncol = 2 * S * p.Tp;
+    float* Hm = workspace;
+    hipLaunchKernelGGL(gcc_masked_h_kernel, dim3(gccnmf_ceil_div(ncol, 256), p.Kp, batch), dim3(256), 0, s, H, argmax, masks, K, p.Kp,
+                       T, p.Tp, p.Np, S, Hm);
+    GCCNMF_CHECK_LAUNCH();
+    const bool tail = (F % 128) == 1;
+    GemmArgs a = {};
+    a.A = W; a.sA = (long)p.Fp * p.Kp; a.lda = p.Kp; a.a_clamp = p.Fp - 1;
+    a.B = Hm; a.sB = (long)p.Kp * ncol; a.ldb = ncol; a.b_clamp = ncol - 4;
+    a.M = tail ? F - 1 : F; a.N = ncol; a.Kd = K;
+    a.tail_row = F - 1;
+    a.batch = batch; a.xcd_affine = 1;
+    a.C = spec; a.sC = 2L * S * p.Fp * p.Tp;   // in float2 units (EPI_PHASE indexes complex elements)
+    a.E0 = V; a.sE0 = (long)p.Fp * p.Np;
+    a.X = (const float2*)X; a.sX = 2L * p.Fp * p.Tp;
+    a.T = T; a.Tp = p.Tp; a.Fp = p.Fp; a.ldv = p.Np;
+    const bool tall = a.M > 128;
+    if (tall) return tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, true>(a, s)
+                          : gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, false>(a, s);
+    return tail ? gccnmf_launch_gemm<1, 4, true, false, EPI_PHASE, true>(a, s)
+                : gccnmf_launch_gemm<1, 4, true, false, EPI_PHASE, false>(a, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+// Batched f32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact-f32, k-ordered
+// fmaf chain), with the KL-NMF / GCC-NMF element-wise work fused into the epilogue.
+//
+// One launch covers every mixture file of a batch.  A workgroup owns a (WM*128) x (WN*64)
+// output tile; each 64-lane wave owns 128 x 64 of it = 4 x 2 MFMA tiles = 128 accumulator
+// registers.  Operand tiles (BK = 16) are staged global -> registers -> LDS with the next
+// tile's global loads in flight under the current tile's MFMAs (one register set, written
+// to LDS after the barrier).  f32 MFMA is 16x slower than bf16 MFMA, so one 16-deep tile
+// is 4096 matrix-pipe cycles per wave against 9 x 16-byte loads per lane: the loop is
+// MFMA-bound by construction and LDS traffic is <10 % of the LDS rate.
+//
+// F = n_fft/2 + 1 is hostile to 32-row MFMA tiles (513 = 16*32 + 1), so the kernel can
+// carry ONE extra output row (the Nyquist bin) on the otherwise idle VALU: TAIL = true
+// computes out[tail_row][:] = A[tail_row][:] . B from the B tile that is in LDS anyway.
+//
+// Operand layouts (what "KC" = reduction-index-contiguous means):
+//   A_KC : A(i,kk) = A[i*lda + kk]   (W in W.H, R in R.H^T)      else A(i,kk) = A[kk*lda + i]  (W^T)
+//   B_KC : B(kk,j) = B[j*ldb + kk]   (H in R.H^T)                else B(kk,j) = B[kk*ldb + j]  (H, R)
+// Reference operations these GEMMs replace: numpy.dot at gccNMF/gccNMFFunctions.py:76,77,150 and the
+// einsum contractions at :92,132-133.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum GemmEpilogue {
+    EPI_STORE = 0,   // C[row][col] = acc
+    EPI_DIV = 1,     // C[row][col] = E0[row][col] / acc                      (R = V / (W.H),  :76/:77)
+    EPI_UPDH = 2,    // C[row][col] = (C[row][col]*E1[row]) * (acc / (E2[row] + alpha + eps))   (H update, :76)
+    EPI_PHASE = 3    // Cx[ic][row][t] = acc * X[c][row][t] / |X|              (:150-151)
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    long sA, sB;               // per-file strides in floats (0 = shared by the batch)
+    int lda, ldb;
+    int M, N, Kd;              // MFMA output rows, output columns, reduction length
+    int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
+    int tiles_m, tiles_n, batch, xcd_affine;
+    const float* bscale;       // optional per-reduction-index scale applied to B while staging (non-KC B only)
+    long s_bscale;
+    int tail_row;              // TAIL: index of the extra VALU-computed output row
+    float* rowsumB;            // optional: rowsumB[j] = sum_kk B(kk, j) (KC B only), written by the tm == 0 blocks
+    long s_rowsumB;
+    float* C;
+    long sC;
+    int ldc;
+    const float* E0;
+    long sE0;
+    const float* E1;
+    long sE1;
+    const float* E2;
+    long sE2;
+    const float2* X;
+    long sX;
+    float alpha, eps;
+    int T, Tp, Fp, ldv;        // EPI_PHASE geometry
+};
+
+template <int EPI>
+__device__ __forceinline__ bool gemm_col_valid(const GemmArgs& p, int col) {
+    if (EPI == EPI_PHASE) {
+        int ic = col / p.Tp;
+        return col < p.N && (col - ic * p.Tp) < p.T;
+    }
+    return col < p.N;
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int file, int row, int col, float acc) {
+    if (EPI == EPI_STORE) {
+        p.C[file * p.sC + (long)row * p.ldc + col] = acc;
+    } else if (EPI == EPI_DIV) {
+        long idx = (long)row * p.ldc + col;
+        p.C[file * p.sC + idx] = p.E0[file * p.sE0 + idx] / acc;
+    } else if (EPI == EPI_UPDH) {
+        long idx = file * p.sC + (long)row * p.ldc + col;
+        float h = p.C[idx];
+        if (p.E1) h *= p.E1[file * p.sE1 + row];
+        float den = p.E2[file * p.sE2 + row] + p.alpha + p.eps;
+        p.C[idx] = h * (acc / den);
+    } else {  // EPI_PHASE
+        int ic = col / p.Tp;
+        int t = col - ic * p.Tp;
+        int c = ic & 1;
+        float2 x = p.X[file * p.sX + ((long)c * p.Fp + row) * p.Tp + t];
+        float v = p.E0[file * p.sE0 + (long)row * p.ldv + c * p.T + t];
+        float2 ph;
+        if (v > 0.f) {
+            ph.x = x.x / v;
+            ph.y = x.y / v;
+        } else {
+            ph.x = 1.f;   // numpy.angle(0) == 0 -> exp(0j) == 1
+            ph.y = 0.f;
+        }
+        float2 o;
+        o.x = acc * ph.x;
+        o.y = acc * ph.y;
+        ((float2*)p.C)[file * p.sC + ((long)ic * p.Fp + row) * p.Tp + t] = o;
+    }
+}
+
+template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
+__global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p) {
+    constexpr int BK = 16;
+    constexpr int BM = WM * 128, BN = WN * 64;
+    constexpr int NT = WM * WN * 64;
+    constexpr int LDA = A_KC ? (BK + 1) : BM;
+    constexpr int LDB = B_KC ? (BK + 1) : BN;
+    constexpr int SA = A_KC ? BM * LDA : BK * BM;
+    constexpr int SB = B_KC ? BN * LDB : BK * BN;
+    constexpr int UA = BM * 4 / NT;   // float4 units of the A tile per thread
+    constexpr int UB = BN * 4 / NT;
+    static_assert(UA >= 1 && UB >= 1 && UA * NT == BM * 4 && UB * NT == BN * 4, "tile/thread mismatch");
+    static_assert(!TAIL || A_KC, "the VALU tail row needs a reduction-contiguous A");
+    static_assert(NT % BN == 0 || BN % NT == 0, "tail mapping");
+
+    __shared__ __attribute__((aligned(16))) float smem[SA + SB + BK];
+    float* sA = smem;
+    float* sB = smem + SA;
+    float* sT = smem + SA + SB;
+
+    // ---- which (file, tile) is this workgroup? ------------------------------------------
+    const int tiles = p.tiles_m * p.tiles_n;
+    int file, tile;
+    if (p.xcd_affine) {
+        // blocks b, b+8, b+16, ... land on XCD b%8 (observed dispatch order): keep every tile of
+        // a file on one XCD so its W/H/R panels are shared through that XCD's L2.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        file = xcd + 8 * (slot / tiles);
+        tile = slot % tiles;
+        if (file >= p.batch) return;
+    } else {
+        file = blockIdx.x / tiles;
+        tile = blockIdx.x - file * tiles;
+    }
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const float* __restrict__ A = p.A + file * p.sA;
+    const float* __restrict__ B = p.B + file * p.sB;
+    const float* __restrict__ bscale = p.bscale ? p.bscale + file * p.s_bscale : nullptr;
+
+    const bool wave_active = (row0 + wm * 128) < p.M;
+    const bool do_tail = TAIL && (tm == 0);
+    const bool do_rowsum = B_KC && (p.rowsumB != nullptr) && (tm == 0);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    float tail_acc = 0.f, rowsum_acc = 0.f;
+
+    float4 ra[UA], rb[UB], rt;
+    float rsc[UB];
+#pragma unroll
+    for (int r = 0; r < UB; ++r) rsc[r] = 1.f;
+    rt = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < UA; ++r) {
+            const int u = tid + NT * r;
+            if (A_KC) {
+                const int row = u >> 2, c4 = u & 3;
+                const int grow = min(row0 + row, p.a_clamp);
+                ra[r] = *(const float4*)(A + (long)grow * p.lda + k0 + 4 * c4);
+            } else {
+                const int kk = u / (BM / 4), c4 = u - kk * (BM / 4);
+                const int gcol = min(row0 + 4 * c4, p.a_clamp);
+                ra[r] = *(const float4*)(A + (long)(k0 + kk) * p.lda + gcol);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UB; ++r) {
+            const int u = tid + NT * r;
+            if (B_KC) {
+                const int row = u >> 2, c4 = u & 3;
+                const int grow = min(col0 + row, p.b_clamp);
+                rb[r] = *(const float4*)(B + (long)grow * p.ldb + k0 + 4 * c4);
+            } else {
+                const int kk = u / (BN / 4), c4 = u - kk * (BN / 4);
+                const int gcol = min(col0 + 4 * c4, p.b_clamp);
+                rb[r] = *(const float4*)(B + (long)(k0 + kk) * p.ldb + gcol);
+                if (bscale) rsc[r] = bscale[k0 + kk];   // consumed in store_tiles: no wait on it here
+            }
+        }
+        if (TAIL) {
+            if (do_tail && tid < 4) rt = *(const float4*)(A + (long)p.tail_row * p.lda + k0 + 4 * tid);
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int r = 0; r < UA; ++r) {
+            const int u = tid + NT * r;
+            if (A_KC) {
+                const int row = u >> 2, c4 = u & 3;
+                float* d = sA + row * LDA + 4 * c4;
+                d[0] = ra[r].x;
+                d[1] = ra[r].y;
+                d[2] = ra[r].z;
+                d[3] = ra[r].w;
+            } else {
+                const int kk = u / (BM / 4), c4 = u - kk * (BM / 4);
+                *(float4*)(sA + kk * BM + 4 * c4) = ra[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UB; ++r) {
+            const int u = tid + NT * r;
+            if (B_KC) {
+                const int row = u >> 2, c4 = u & 3;
+                float* d = sB + row * LDB + 4 * c4;
+                d[0] = rb[r].x;
+                d[1] = rb[r].y;
+                d[2] = rb[r].z;
+                d[3] = rb[r].w;
+            } else {
+                const int kk = u / (BN / 4), c4 = u - kk * (BN / 4);
+                float4 v = rb[r];
+                if (bscale) {
+                    v.x *= rsc[r];
+                    v.y *= rsc[r];
+                    v.z *= rsc[r];
+                    v.w *= rsc[r];
+                }
+                *(float4*)(sB + kk * BN + 4 * c4) = v;
+            }
+        }
+        if (TAIL) {
+            if (do_tail && tid < 4) *(float4*)(sT + 4 * tid) = rt;
+        }
+    };
+
+    const int nkt = (p.Kd + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tiles((kt + 1) * BK);   // in flight under this tile's MFMAs
+
+        if (wave_active) {
+#pragma unroll
+            for (int pp = 0; pp < BK / 2; ++pp) {
+                const int kk = 2 * pp + hh;
+                float a[4], b[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    a[m] = A_KC ? sA[(wm * 128 + m * 32 + l31) * LDA + kk] : sA[kk * BM + wm * 128 + m * 32 + l31];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    b[n] = B_KC ? sB[(wn * 64 + n * 32 + l31) * LDB + kk] : sB[kk * BN + wn * 64 + n * 32 + l31];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (TAIL) {
+            if (do_tail) {
+                // NT >= BN: NT/BN thread groups split the 16 reduction steps; NT < BN never happens with TAIL configs
+                constexpr int G = (NT >= BN) ? NT / BN : 1;
+                constexpr int PER = BK / G;
+                const int j = tid % BN, g = tid / BN;
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    const int kk = g * PER + e;
+                    const float bv = B_KC ? sB[j * LDB + kk] : sB[kk * BN + j];
+                    tail_acc = fmaf(sT[kk], bv, tail_acc);
+                }
+            }
+        }
+        if (B_KC) {
+            if (do_rowsum) {
+                constexpr int PERT = (NT >= BN) ? NT / BN : 1;   // threads per atom row
+                constexpr int CNT = BK / PERT;
+                const int j = tid / PERT, q = tid - j * PERT;
+                if (j < BN) {
+#pragma unroll
+                    for (int e = 0; e < CNT; ++e) rowsum_acc += sB[j * LDB + q * CNT + e];
+                }
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) store_tiles();
+        __syncthreads();
+    }
+
+    // ---- epilogue: MFMA C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------
+    if (wave_active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = col0 + wn * 64 + n * 32 + l31;
+                const bool cv = gemm_col_valid<EPI>(p, col);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (cv && row < p.M) gemm_epilogue<EPI>(p, file, row, col, acc[m][n][r]);
+                }
+            }
+    }
+    if (TAIL) {
+        if (do_tail) {   // block-uniform
+            constexpr int G = (NT >= BN) ? NT / BN : 1;
+            sA[tid] = tail_acc;     // sA is free after the final barrier of the k loop
+            __syncthreads();
+            if (tid < BN) {
+                float s = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; ++g) s += sA[g * BN + tid];
+                const int col = col0 + tid;
+                if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, file, p.tail_row, col, s);
+            }
+        }
+    }
+    if (B_KC) {
+        if (do_rowsum) {
+            constexpr int PERT = (NT >= BN) ? NT / BN : 1;
+            float s = rowsum_acc;
+            if (PERT >= 2) s += __shfl_xor(s, 1);
+            if (PERT >= 4) s += __shfl_xor(s, 2);
+            const int j = tid / PERT, q = tid - j * PERT;
+            if (q == 0 && j < BN && (col0 + j) < p.N) p.rowsumB[file * p.s_rowsumB + col0 + j] = s;
+        }
+    }
+}
+
+template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
+static int gccnmf_launch_gemm(GemmArgs a, hipStream_t stream) {
+    constexpr int BM = WM * 128, BN = WN * 64, NT = WM * WN * 64;
+    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
+    if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;   // float4 staging
+    a.tiles_m = gccnmf_ceil_div(a.M, BM);
+    a.tiles_n = gccnmf_ceil_div(a.N, BN);
+    const int tiles = a.tiles_m * a.tiles_n;
+    int grid;
+    if (a.xcd_affine && a.batch >= 8) {
+        a.xcd_affine = 1;
+        grid = 8 * gccnmf_ceil_div(a.batch, 8) * tiles;
+    } else {
+        a.xcd_affine = 0;
+        grid = a.batch * tiles;
+    }
+    hipLaunchKernelGGL((gccnmf_gemm_kernel<WM, WN, A_KC, B_KC, EPI, TAIL>), dim3(grid), dim3(NT), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}

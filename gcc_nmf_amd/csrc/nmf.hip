@@ -1,0 +1,385 @@
+// KL-NMF multiplicative updates on gfx950 -- the >98 %-of-FLOPs part of the GCC-NMF path.
+// Reference: performKLNMF, gccNMF/gccNMFFunctions.py:69-83.
+//
+// One iteration (reference lines in brackets) is five launches that cover the whole batch:
+//   K1  R  = V / (W . (s*H))                     MFMA GEMM + divide epilogue            [:76 inner]
+//   K2  H  = (s*H) * (W^T . R) / (colsum W + alpha + eps)   MFMA GEMM + update epilogue [:76]
+//   K3  R  = V / (W . H)                         (new H)                                [:77 inner]
+//   K4a U  = R . H^T ,  rowsumH = sum_n H        MFMA GEMM, row sums from the staged B  [:77]
+//   K4b W  = normalise(W * U / rowsumH); s = atom norms; colsumW = sum_f W             [:77,:79-80]
+// The compensating rescale H *= norms (:81) is NOT a separate pass over H: it is the vector s,
+// applied while K1 stages its B operand and inside K2's epilogue (which rewrites H anyway).
+// gccnmf_klnmf materialises it once after the last iteration.
+#include "gemm_mfma.h"
+
+extern "C" {
+int gccnmf_version(void) { return 100; }
+
+int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
+    if (F < 2 || T < 1 || K < 1 || !Fp || !Kp || !Np || !Tp) return GCCNMF_ERR_ARG;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, K);
+    *Fp = p.Fp;
+    *Kp = p.Kp;
+    *Np = p.Np;
+    *Tp = p.Tp;
+    return GCCNMF_OK;
+}
+}
+
+// ------------------------------------------------------------------------------------------
+// small K-vector kernels
+// ------------------------------------------------------------------------------------------
+// colsumW[k] = sum_f W[f][k]; hscale[k] = 1.   grid = batch * Kp/64, 256 threads.
+__global__ __launch_bounds__(256) void nmf_prepare_kernel(const float* __restrict__ W, float* __restrict__ colsumW,
+                                                          float* __restrict__ hscale, int F, int Fp, int Kp) {
+    __shared__ float red[256];
+    const int chunks = Kp / 64;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = ch * 64 + c;
+    const float* Wb = W + (long)b * Fp * Kp;
+    float s = 0.f;
+    for (int f = q; f < F; f += 4) s += Wb[(long)f * Kp + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0) {
+        colsumW[(long)b * Kp + k] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+        hscale[(long)b * Kp + k] = 1.f;
+    }
+}
+
+// W update + unit-L2 atom normalisation (gccNMFFunctions.py:77,79-80):
+//   Wt = W * (U / rowsumH[k]);  norm[k] = sqrt(sum_f Wt^2);  W = Wt / norm;  hscale = norm;  colsumW = sum_f W
+// grid = batch * Kp/64, 256 threads = 64 atoms x 4 row phases; W and U are read twice (L2-resident
+// 2 x 131 KB per block) instead of keeping F/4 values per thread in registers.
+__global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W, const float* __restrict__ U,
+                                                           const float* __restrict__ rowsumH, float* __restrict__ colsumW,
+                                                           float* __restrict__ hscale, int F, int Fp, int K, int Kp,
+                                                           long sW, long sU, long sVec, long sRowsum) {
+    __shared__ float red[256];
+    const int chunks = Kp / 64;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = ch * 64 + c;
+    const bool valid = k < K;          // padded atoms stay exactly zero
+    float* Wb = W + b * sW;
+    const float* Ub = U + b * sU;
+    const float rs = valid ? rowsumH[b * sRowsum + k] : 1.f;
+    float ss = 0.f;
+    if (valid)
+        for (int f = q; f < F; f += 4) {
+            const float wt = Wb[(long)f * Kp + k] * (Ub[(long)f * Kp + k] / rs);
+            ss = fmaf(wt, wt, ss);
+        }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    const float norm = sqrtf((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]));
+    __syncthreads();
+    float cs = 0.f;
+    if (valid)
+        for (int f = q; f < F; f += 4) {
+            const long i = (long)f * Kp + k;
+            const float wn = (Wb[i] * (Ub[i] / rs)) / norm;
+            Wb[i] = wn;
+            cs += wn;
+        }
+    red[threadIdx.x] = cs;
+    __syncthreads();
+    if (q == 0 && valid) {
+        colsumW[b * sVec + k] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+        hscale[b * sVec + k] = norm;
+    }
+}
+
+// H[k][:] *= hscale[k].  grid = batch * K rows, 256 threads.  (sScale = 0: one shared scale vector)
+__global__ __launch_bounds__(256) void nmf_scale_h_kernel(float* __restrict__ H, const float* __restrict__ hscale, long sScale,
+                                                          int K, int Kp, int Np) {
+    const int b = blockIdx.x / K, k = blockIdx.x - b * K;
+    const float s = hscale[b * sScale + k];
+    float4* row = (float4*)(H + ((long)b * Kp + k) * Np);
+    for (int i = threadIdx.x; i < Np / 4; i += 256) {
+        float4 v = row[i];
+        v.x *= s;
+        v.y *= s;
+        v.z *= s;
+        v.w *= s;
+        row[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nmf_fill_kernel(float* __restrict__ p, float v, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// out[i] = sum_b in[b*stride + i], files added in ascending order (deterministic).
+__global__ __launch_bounds__(256) void nmf_reduce_files_kernel(const float* __restrict__ in, long stride, int batch, long n,
+                                                               float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < batch; ++b) s += in[b * stride + i];
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM dispatch: tall <4,1> tile for >128 output rows, wide <1,4> otherwise
+// ------------------------------------------------------------------------------------------
+template <bool A_KC, bool B_KC, int EPI>
+static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
+    const bool tall = a.M > 128;
+    if (A_KC) {
+        if (tall) return tail ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false>(a, s);
+        return tail ? gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, false>(a, s);
+    }
+    if (tail) return GCCNMF_ERR_ARG;
+    return tall ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false>(a, s) : gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, false>(a, s);
+}
+
+struct NmfGeom {
+    int F, N, K, Fp, Kp, Np;
+    int Fm;         // rows computed on the matrix cores
+    bool tail;      // F % 128 == 1: the last bin rides on the VALU
+    long sV, sW, sH, sU;
+};
+
+static NmfGeom make_geom(int F, int N, int K) {
+    NmfGeom g;
+    GccNmfPitches p = gccnmf_make_pitches(F, 1, K);
+    g.F = F; g.N = N; g.K = K;
+    g.Fp = p.Fp; g.Kp = p.Kp; g.Np = gccnmf_round_up(N, 64);
+    g.tail = (F % 128) == 1 && F > 1;
+    g.Fm = g.tail ? F - 1 : F;
+    g.sV = (long)g.Fp * g.Np;
+    g.sW = (long)g.Fp * g.Kp;
+    g.sH = (long)g.Kp * g.Np;
+    g.sU = (long)g.Fp * g.Kp;
+    return g;
+}
+
+// R = V / (W . (bscale*H))
+static int launch_wh_div(const NmfGeom& g, const float* V, const float* W, long sW, const float* H, const float* hscale,
+                         long sScale, float* R, int batch, int xcd, hipStream_t s) {
+    GemmArgs a = {};
+    a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Np - 4;
+    a.M = g.Fm; a.N = g.N; a.Kd = g.K;
+    a.batch = batch; a.xcd_affine = xcd;
+    a.bscale = hscale; a.s_bscale = sScale;
+    a.tail_row = g.F - 1;
+    a.C = R; a.sC = g.sV; a.ldc = g.Np;
+    a.E0 = V; a.sE0 = g.sV;
+    return dispatch_gemm<true, false, EPI_DIV>(a, g.tail, s);
+}
+
+// H = (hscale*H) * (W^T . R) / (colsumW + alpha + eps)
+static int launch_update_h(const NmfGeom& g, const float* W, long sW, const float* R, float* H, const float* hscale,
+                           long sScale, const float* colsumW, long sVec, float alpha, float eps, int batch, int xcd,
+                           hipStream_t s) {
+    GemmArgs a = {};
+    a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Kp - 4;
+    a.B = R; a.sB = g.sV; a.ldb = g.Np; a.b_clamp = g.Np - 4;
+    a.M = g.K; a.N = g.N; a.Kd = g.F;
+    a.batch = batch; a.xcd_affine = xcd;
+    a.C = H; a.sC = g.sH; a.ldc = g.Np;
+    a.E1 = hscale; a.sE1 = sScale;
+    a.E2 = colsumW; a.sE2 = sVec;
+    a.alpha = alpha; a.eps = eps;
+    return dispatch_gemm<false, false, EPI_UPDH>(a, false, s);
+}
+
+// U = R . H^T, rowsumH = sum_n H
+static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U, float* rowsumH, int batch, int xcd,
+                      hipStream_t s) {
+    GemmArgs a = {};
+    a.A = R; a.sA = g.sV; a.lda = g.Np; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
+    a.M = g.Fm; a.N = g.K; a.Kd = g.N;
+    a.batch = batch; a.xcd_affine = xcd;
+    a.tail_row = g.F - 1;
+    a.rowsumB = rowsumH; a.s_rowsumB = g.Kp;
+    a.C = U; a.sC = g.sU; a.ldc = g.Kp;
+    return dispatch_gemm<true, true, EPI_STORE>(a, g.tail, s);
+}
+
+extern "C" {
+
+long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
+    if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
+    NmfGeom g = make_geom(F, N, K);
+    return (long)batch * (g.sV + g.sU + 3L * g.Kp);
+}
+
+// One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
+// check each kernel in isolation.  stage: 0 prepare | 1 K1 | 2 K2 | 3 K3 | 4 K4a | 5 K4b | 6 final H rescale
+static int klnmf_stage(int stage, const float* V, float* W, float* H, float* workspace, const NmfGeom& g, int batch,
+                       float alpha, float eps, int flags, hipStream_t s) {
+    float* R = workspace;
+    float* U = R + (long)batch * g.sV;
+    float* colsumW = U + (long)batch * g.sU;
+    float* rowsumH = colsumW + (long)batch * g.Kp;
+    float* hscale = rowsumH + (long)batch * g.Kp;
+    const int xcd = (flags & 1) ? 0 : 1;
+    const int vec_grid = batch * (g.Kp / 64);
+    switch (stage) {
+        case 0:
+            // R's padding (rows >= F, columns >= N) must be zero: it is a reduction operand of K2 and K4a.
+            if (hipMemsetAsync(R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+            hipLaunchKernelGGL(nmf_prepare_kernel, dim3(vec_grid), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
+            break;
+        case 1: return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
+        case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
+        case 3: return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
+        case 4: return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
+        case 5:
+            hipLaunchKernelGGL(nmf_update_w_kernel, dim3(vec_grid), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, g.F, g.Fp,
+                               g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp);
+            break;
+        case 6:
+            hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.Kp, g.Np);
+            break;
+        default: return GCCNMF_ERR_ARG;
+    }
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
+                       float sparsity_alpha, float epsilon, int flags, int stage, void* stream) {
+    if (!V || !W || !H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    return klnmf_stage(stage, V, W, H, workspace, make_geom(F, N, K), batch, sparsity_alpha, epsilon, flags, (hipStream_t)stream);
+}
+
+int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch, int iterations,
+                 float sparsity_alpha, float epsilon, int flags, void* stream) {
+    if (!V || !W || !H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1 || iterations < 0) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, N, K);
+    int rc;
+    if ((rc = klnmf_stage(0, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
+    for (int it = 0; it < iterations; ++it)
+        for (int stage = 1; stage <= 5; ++stage)
+            if ((rc = klnmf_stage(stage, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
+    return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
+}
+
+// ---- shared dictionary (one W for every file / rank) ------------------------------------------
+// workspace: R [batch][Fp][Np] | Upart [batch][Fp][Kp] | rowsum_part [batch][Kp] | colsumW [Kp] | hscale [Kp]
+struct SharedWs {
+    float *R, *Upart, *rowsum_part, *colsumW, *hscale;
+};
+static SharedWs carve_shared(float* ws, const NmfGeom& g, int batch) {
+    SharedWs w;
+    w.R = ws;
+    w.Upart = w.R + (long)batch * g.sV;
+    w.rowsum_part = w.Upart + (long)batch * g.sU;
+    w.colsumW = w.rowsum_part + (long)batch * g.Kp;
+    w.hscale = w.colsumW + g.Kp;
+    return w;
+}
+
+long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch) {
+    if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
+    NmfGeom g = make_geom(F, N, K);
+    return (long)batch * (g.sV + g.sU + g.Kp) + 2L * g.Kp;
+}
+
+long gccnmf_klnmf_shared_partial_floats(int F, int K) {
+    if (F < 2 || K < 1) return -1;
+    NmfGeom g = make_geom(F, 1, K);
+    return g.sU + g.Kp;
+}
+
+int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, int K, int batch, void* stream) {
+    if (!W || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, N, K);
+    SharedWs w = carve_shared(workspace, g, batch);
+    if (hipMemsetAsync(w.R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 64), dim3(256), 0, s, W, w.colsumW, w.hscale, g.F, g.Fp, g.Kp);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* workspace, float* partial, int F, int N,
+                               int K, int batch, float sparsity_alpha, float epsilon, void* stream) {
+    if (!V || !W || !H || !workspace || !partial || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, N, K);
+    SharedWs w = carve_shared(workspace, g, batch);
+    int rc;
+    if ((rc = launch_wh_div(g, V, W, 0, H, w.hscale, 0, w.R, batch, 0, s))) return rc;
+    if ((rc = launch_update_h(g, W, 0, w.R, H, w.hscale, 0, w.colsumW, 0, sparsity_alpha, epsilon, batch, 0, s))) return rc;
+    // H now carries the previous normalisation: the lazy scale is spent
+    hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.hscale, 1.f, (long)g.Kp);
+    GCCNMF_CHECK_LAUNCH();
+    if ((rc = launch_wh_div(g, V, W, 0, H, nullptr, 0, w.R, batch, 0, s))) return rc;
+    if ((rc = launch_rht(g, w.R, H, w.Upart, w.rowsum_part, batch, 0, s))) return rc;
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)gccnmf_ceil_div((int)g.sU, 256)), dim3(256), 0, s, w.Upart, g.sU,
+                       batch, g.sU, partial);
+    GCCNMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.rowsum_part, (long)g.Kp,
+                       batch, (long)g.Kp, partial + g.sU);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch, void* stream) {
+    if (!W || !workspace || !partial || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, N, K);
+    SharedWs w = carve_shared(workspace, g, batch);
+    hipLaunchKernelGGL(nmf_update_w_kernel, dim3(g.Kp / 64), dim3(256), 0, s, W, partial, partial + g.sU, w.colsumW, w.hscale,
+                       g.F, g.Fp, g.K, g.Kp, 0L, 0L, 0L, 0L);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream) {
+    if (!H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, N, K);
+    SharedWs w = carve_shared(workspace, g, batch);
+    hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, w.hscale, 0L, g.K, g.Kp, g.Np);
+    GCCNMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.hscale, 1.f, (long)g.Kp);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc,
+                      int a_clamp, int b_clamp, int layout, int batch, long sA, long sB, long sC, const float* bscale,
+                      float* rowsumB, void* stream) {
+    GemmArgs a = {};
+    a.A = A; a.sA = sA; a.lda = lda; a.a_clamp = a_clamp;
+    a.B = B; a.sB = sB; a.ldb = ldb; a.b_clamp = b_clamp;
+    const bool tail = layout & 4;
+    a.M = tail ? M - 1 : M; a.N = N; a.Kd = Kd;
+    a.tail_row = M - 1;
+    a.batch = batch; a.xcd_affine = 1;
+    a.bscale = bscale; a.s_bscale = 0;
+    a.rowsumB = rowsumB; a.s_rowsumB = N;
+    a.C = C; a.sC = sC; a.ldc = ldc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = layout & 8;
+    switch (layout & 3) {
+        case 0:
+            if (tail) return GCCNMF_ERR_ARG;
+            return wide ? gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s)
+                        : gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s);
+        case 1:
+            if (wide) return tail ? gccnmf_launch_gemm<1, 4, true, false, EPI_STORE, true>(a, s)
+                                  : gccnmf_launch_gemm<1, 4, true, false, EPI_STORE, false>(a, s);
+            return tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true>(a, s)
+                        : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false>(a, s);
+        case 3:
+            if (wide) return tail ? gccnmf_launch_gemm<1, 4, true, true, EPI_STORE, true>(a, s)
+                                  : gccnmf_launch_gemm<1, 4, true, true, EPI_STORE, false>(a, s);
+            return tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true>(a, s)
+                        : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false>(a, s);
+        default:
+            return GCCNMF_ERR_UNSUPPORTED;   // (A non-KC, B KC) is not used by the path
+    }
+}
+
+}  // extern "C"

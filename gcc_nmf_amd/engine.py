@@ -1,0 +1,248 @@
+"""Device-resident GCC-NMF pipeline for a batch of equally shaped stereo mixtures.
+
+Python here is plumbing only: PyTorch-ROCm owns the HBM allocations and the HIP
+stream, every stage is one (or a few) calls into libgccnmf_hip.so through
+``_hip`` (C ABI, include/gccnmf_hip.h).  Nothing in this module computes on the
+host except the input-independent constant tables (window, FFT twiddles,
+steering cos/sin, MT19937 initial W/H), which the reference also derives on the
+host (gccNMF/gccNMFFunctions.py:53-59, :70-73, :87-89).
+
+Stage order = gccNMF/runGCCNMF.py:36-52.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+
+SPEED_OF_SOUND_IN_METRES_PER_SECOND = 340.29          # gccNMF/gccNMFFunctions.py:38
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def num_frames(n_samples, n_fft, hop):
+    """gccNMF/librosaSTFT.py:425."""
+    return 1 + int((n_samples - n_fft) / hop)
+
+
+def klnmf_initial_factors(F, N, K, epsilon=1e-16, seedValue=0):
+    """gccNMF/gccNMFFunctions.py:70-73: legacy MT19937, W before H, float64 -> float32, + epsilon."""
+    rs = np.random.RandomState(seedValue)
+    W = rs.random_sample((F, K)).astype(np.float32) + epsilon
+    H = rs.random_sample((K, N)).astype(np.float32) + epsilon
+    return W.astype(np.float32), H.astype(np.float32)
+
+
+def fft_twiddles(n_fft):
+    k = np.arange(n_fft // 2, dtype=np.float64)
+    tw = np.exp(-2j * np.pi * k / n_fft).astype(np.complex64)
+    return np.ascontiguousarray(tw).view(np.float32)
+
+
+def steering_tables(frequenciesInHz, tdoasInSeconds, Fp, Dp):
+    """cos / sin of 2*pi*f*tau, evaluated in float64 like the reference's
+    exp(outer(f, -2j*pi*tau)) (gccNMF/gccNMFFunctions.py:89,127), zero padded to [2][Fp][Dp]."""
+    E = np.exp(np.outer(np.asarray(frequenciesInHz, np.float64), -(2j * np.pi) * np.asarray(tdoasInSeconds, np.float64)))
+    F, D = E.shape
+    trig = np.zeros((2, Fp, Dp), np.float32)
+    trig[0, :F, :D] = E.real
+    trig[1, :F, :D] = -E.imag
+    return trig
+
+
+class Geometry(object):
+    """Padded storage geometry; the pitches come from the library so host and kernels cannot disagree."""
+
+    def __init__(self, F, T, K, D=1, S=1):
+        import ctypes
+        vals = [ctypes.c_int() for _ in range(4)]
+        _hip.check(_hip.lib().gccnmf_pitches(F, T, K, *[ctypes.byref(v) for v in vals]), 'gccnmf_pitches')
+        self.F, self.T, self.K, self.D, self.S = F, T, K, D, S
+        self.N = 2 * T
+        self.Fp, self.Kp, self.Np, self.Tp = [v.value for v in vals]
+        self.Dp = -(-D // 64) * 64
+
+
+def padded(host, shape, device, dtype=torch.float32):
+    """Upload ``host`` (ndarray) into the top-left corner of a zero tensor of ``shape``."""
+    t = torch.zeros(shape, dtype=dtype, device=device)
+    src = torch.from_numpy(np.ascontiguousarray(host))
+    idx = tuple(slice(0, n) for n in host.shape)
+    t[idx] = src.to(device)
+    return t
+
+
+class GCCNMFEngine(object):
+    """All buffers of one batch shape, allocated once; ``separate()`` runs the full path on device."""
+
+    def __init__(self, n_samples, sampleRate=16000, windowSize=1024, hopSize=256, numTDOAs=128,
+                 microphoneSeparationInMetres=1.0, numTargets=3, dictionarySize=128, numIterations=100,
+                 sparsityAlpha=0, epsilon=1e-16, seedValue=0, batch=1, windowFunction=np.hanning,
+                 device='cuda:0', klnmf_flags=0):
+        if not torch.cuda.is_available():
+            raise _hip.HipLibraryError('no ROCm device visible: the GCC-NMF HIP path has no CPU fallback')
+        self.lib = _hip.lib()
+        self.device = torch.device(device)
+        self.n_samples, self.sampleRate = int(n_samples), sampleRate
+        self.n_fft, self.hop = int(windowSize), int(hopSize)
+        self.iters, self.alpha, self.eps, self.seed = int(numIterations), float(sparsityAlpha), float(epsilon), seedValue
+        self.batch = int(batch)
+        self.d = microphoneSeparationInMetres
+        self.klnmf_flags = klnmf_flags
+        F = self.n_fft // 2 + 1
+        T = num_frames(self.n_samples, self.n_fft, self.hop)
+        if T < 2:
+            raise ValueError('Buffer is too short (n=%d) for frame_length=%d' % (n_samples, self.n_fft))
+        self.g = g = Geometry(F, T, int(dictionarySize), int(numTDOAs), int(numTargets))
+        self.L = self.hop * (T - 1)
+        dev, B = self.device, self.batch
+        f32 = torch.float32
+
+        with torch.cuda.device(dev):
+            # constant tables
+            self.window = torch.from_numpy(np.asarray(windowFunction(self.n_fft), np.float64).astype(np.float32)).to(dev)
+            self.twiddle = torch.from_numpy(fft_twiddles(self.n_fft)).to(dev)
+            maxTDOA = self.d / SPEED_OF_SOUND_IN_METRES_PER_SECOND
+            self.tdoasInSeconds = np.linspace(-maxTDOA, maxTDOA, g.D)
+            self.frequenciesInHz = np.linspace(0, sampleRate / 2.0, F)
+            self.trig = torch.from_numpy(steering_tables(self.frequenciesInHz, self.tdoasInSeconds, g.Fp, g.Dp)).to(dev)
+            W0, H0 = klnmf_initial_factors(F, g.N, g.K, self.eps, seedValue)
+            self.W0 = padded(W0, (g.Fp, g.Kp), dev)
+            self.H0 = padded(H0, (g.Kp, g.Np), dev)
+
+            z = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+            self.x = z(B, 2, self.n_samples)
+            self.X = z(B, 2, g.Fp, g.Tp, 2)
+            self.V = z(B, g.Fp, g.Np)
+            self.CC = z(B, 2, g.Fp, g.Tp)
+            self.W = z(B, g.Fp, g.Kp)
+            self.H = z(B, g.Kp, g.Np)
+            self.ws_nmf = z(self.lib.gccnmf_klnmf_workspace_floats(F, g.N, g.K, B))
+            self.ang = z(B, g.Dp, g.Tp)
+            self.mean_ang = torch.zeros((B, g.Dp), dtype=torch.float64, device=dev)
+            self.tdoa_idx = torch.zeros((B, g.S), dtype=torch.int32, device=dev)
+            self.status = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.ws_scores = z(self.lib.gccnmf_scores_workspace_floats(F, T, g.S, B))
+            self.scores = z(B, g.Kp, g.S * g.Tp)
+            self.argmax = torch.zeros((B, g.Kp, g.Tp), dtype=torch.uint8, device=dev)
+            self.ws_rec = z(self.lib.gccnmf_reconstruct_workspace_floats(T, g.K, g.S, B))
+            self.spec = z(B, 2 * g.S, g.Fp, g.Tp, 2)
+            self.frames = z(B, 2 * g.S, T, self.n_fft)
+            self.y = z(B, g.S, 2, self.L)
+
+    # ---- stages (each asynchronous on the current torch stream) ---------------------------------
+    def stft(self):
+        g = self.g
+        _hip.check(self.lib.gccnmf_stft_stereo(_ptr(self.x), 2 * self.n_samples, self.n_samples, self.n_fft, self.hop, g.T,
+                                               self.batch, _ptr(self.window), _ptr(self.twiddle), _ptr(self.X), _ptr(self.V),
+                                               _ptr(self.CC), _stream()), 'gccnmf_stft_stereo')
+
+    def klnmf(self):
+        g = self.g
+        self.W.copy_(self.W0.unsqueeze(0).expand_as(self.W))
+        self.H.copy_(self.H0.unsqueeze(0).expand_as(self.H))
+        _hip.check(self.lib.gccnmf_klnmf(_ptr(self.V), _ptr(self.W), _ptr(self.H), _ptr(self.ws_nmf), g.F, g.N, g.K, self.batch,
+                                         self.iters, self.alpha, self.eps, self.klnmf_flags, _stream()), 'gccnmf_klnmf')
+
+    def localize(self):
+        g = self.g
+        _hip.check(self.lib.gccnmf_angular_spectrogram(_ptr(self.CC), _ptr(self.trig), g.F, g.T, g.D, self.batch, _ptr(self.ang),
+                                                       _ptr(self.mean_ang), _stream()), 'gccnmf_angular_spectrogram')
+        _hip.check(self.lib.gccnmf_pick_tdoa_peaks(_ptr(self.mean_ang), g.D, g.Dp, g.S, self.batch, _ptr(self.tdoa_idx),
+                                                   _ptr(self.status), _stream()), 'gccnmf_pick_tdoa_peaks')
+
+    def masks(self):
+        g = self.g
+        _hip.check(self.lib.gccnmf_target_scores_masks(_ptr(self.CC), _ptr(self.trig), _ptr(self.tdoa_idx), _ptr(self.W), g.F, g.T,
+                                                       g.K, g.D, g.S, self.batch, _ptr(self.ws_scores), _ptr(self.scores),
+                                                       _ptr(self.argmax), _stream()), 'gccnmf_target_scores_masks')
+
+    def reconstruct(self):
+        g = self.g
+        _hip.check(self.lib.gccnmf_reconstruct(_ptr(self.W), _ptr(self.H), _ptr(self.argmax), 0, _ptr(self.X), _ptr(self.V), g.F,
+                                               g.T, g.K, g.S, self.batch, _ptr(self.ws_rec), _ptr(self.spec), _stream()),
+                   'gccnmf_reconstruct')
+
+    def istft(self):
+        g = self.g
+        gain = np.float32(self.hop / float(self.n_fft) * 2)           # gccNMFFunctions.py:155
+        _hip.check(self.lib.gccnmf_istft_ola(_ptr(self.spec), 2 * g.S, self.n_fft, self.hop, g.T, self.batch, _ptr(self.window),
+                                             _ptr(self.twiddle), gain, 1, _ptr(self.frames), _ptr(self.y), _stream()),
+                   'gccnmf_istft_ola')
+
+    def run(self):
+        """samples already in ``self.x`` -> separated waveforms in ``self.y`` (all on device, asynchronous)."""
+        self.stft()
+        self.klnmf()
+        self.localize()
+        self.masks()
+        self.reconstruct()
+        self.istft()
+
+    # ---- host <-> device -------------------------------------------------------------------------
+    def upload(self, stereoSamples):
+        x = np.asarray(stereoSamples, dtype=np.float32)
+        if x.ndim == 2:
+            x = x[None]
+        if x.shape != (self.batch, 2, self.n_samples):
+            raise ValueError('expected samples of shape %s, got %s' % ((self.batch, 2, self.n_samples), x.shape))
+        if not np.isfinite(x).all():
+            raise ValueError('Audio buffer is not finite everywhere')      # librosaSTFT.py:488-489
+        self.x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
+
+    def separate(self, stereoSamples):
+        """(batch, 2, n) float32 host samples -> (batch, S, 2, hop*(T-1)) float32 host waveforms."""
+        self.upload(stereoSamples)
+        self.run()
+        y = self.y.cpu().numpy()
+        self.check_status()
+        return y
+
+    def check_status(self):
+        st = self.status.cpu().numpy()
+        if st.any():
+            raise ValueError('fewer than %d angular-spectrum peaks in file(s) %s' % (self.g.S, np.nonzero(st)[0].tolist()))
+
+    # ---- views of device results in the reference's shapes ------------------------------------------
+    def get_X(self):
+        g = self.g
+        return torch.view_as_complex(self.X)[:, :, :g.F, :g.T].cpu().numpy()
+
+    def get_V(self):
+        g = self.g
+        return self.V[:, :g.F, :g.N].cpu().numpy()
+
+    def get_C(self):
+        g = self.g
+        c = self.CC[:, :, :g.F, :g.T].cpu().numpy()
+        return (c[:, 0] + 1j * c[:, 1]).astype(np.complex64)
+
+    def get_WH(self):
+        g = self.g
+        return self.W[:, :g.F, :g.K].cpu().numpy(), self.H[:, :g.K, :g.N].cpu().numpy()
+
+    def get_angular(self):
+        g = self.g
+        return self.ang[:, :g.D, :g.T].cpu().numpy(), self.mean_ang[:, :g.D].cpu().numpy()
+
+    def get_tdoa_indexes(self):
+        return self.tdoa_idx.cpu().numpy()
+
+    def get_scores(self):
+        g = self.g
+        s = self.scores.view(self.batch, g.Kp, g.S, g.Tp)[:, :g.K, :, :g.T]
+        return s.permute(0, 2, 1, 3).contiguous().cpu().numpy()
+
+    def get_argmax(self):
+        g = self.g
+        return self.argmax[:, :g.K, :g.T].cpu().numpy()
+
+    def get_spec(self):
+        g = self.g
+        s = torch.view_as_complex(self.spec)[:, :, :g.F, :g.T].cpu().numpy()
+        return s.reshape(self.batch, g.S, 2, g.F, g.T)

@@ -1,0 +1,258 @@
+"""Drop-in replacement for the reference's ``gccNMF/gccNMFFunctions.py`` on MI355X.
+
+Same function names, positional order, defaults, return shapes and dtypes as the
+reference (each docstring cites the reference lines it replaces); NumPy arrays in,
+NumPy arrays out.  The arithmetic of every function on the hot path runs in
+libgccnmf_hip.so (hand-written gfx950 kernels, C ABI in include/gccnmf_hip.h);
+there is no CPU fallback -- without the library or a GPU the functions raise
+``HipLibraryError``.  Each call uploads its arguments and downloads its result;
+use ``gcc_nmf_amd.engine.GCCNMFEngine`` to keep a whole batch resident in HBM.
+
+The module-level NumPy names below are part of the interface: the reference's
+driver does ``from gccNMFFunctions import *`` and then uses ``hanning``,
+``linspace``, ``float32``, ``concatenate``, ``array``, ``hsplit``, ``mean`` ...
+without importing them (gccNMF/runGCCNMF.py:27-46).
+"""
+import logging
+from os.path import basename, join
+
+import numpy as np
+import torch
+from numpy import hanning, array, squeeze, arange, concatenate, sqrt, sum, dot, newaxis, linspace, \
+    exp, outer, pi, einsum, argsort, mean, hsplit, zeros, empty, min, max, isnan, all, nanargmax, empty_like, \
+    where, zeros_like, angle, arctan2, int16, float32, complex64, argmax, take
+from numpy.random import random, seed
+from scipy.signal import argrelmax
+
+from . import _hip
+from .engine import Geometry, padded, fft_twiddles, steering_tables, _ptr, _stream
+from .librosaSTFT import stft, istft, ParameterError, _window_vector, _istft_device
+from .wavfile import wavread, wavwrite
+
+SPEED_OF_SOUND_IN_METRES_PER_SECOND = 340.29
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _hip.HipLibraryError('no ROCm device visible: gcc_nmf_amd has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+# ---- pass-throughs (gccNMF/gccNMFFunctions.py:40-59) ------------------------------------------------
+def getMixtureFileName(mixtureFileNamePrefix):
+    return mixtureFileNamePrefix + '_mix.wav'
+
+
+def getSourceEstimateFileName(mixtureFileNamePrefix, targetIndex):
+    return mixtureFileNamePrefix + '_sim_%d.wav' % (targetIndex + 1)
+
+
+def loadMixtureSignal(mixtureFileName):
+    return wavread(mixtureFileName)
+
+
+def getMaxTDOA(microphoneSeparationInMetres):
+    return microphoneSeparationInMetres / SPEED_OF_SOUND_IN_METRES_PER_SECOND
+
+
+def getTDOAsInSeconds(microphoneSeparationInMetres, numTDOAs):
+    maxTDOA = getMaxTDOA(microphoneSeparationInMetres)
+    return linspace(-maxTDOA, maxTDOA, numTDOAs)
+
+
+def getFrequenciesInHz(sampleRate, numFrequencies):
+    return linspace(0, sampleRate / 2, numFrequencies)
+
+
+# ---- hot path ------------------------------------------------------------------------------------------
+def computeComplexMixtureSpectrogram(stereoSamples, windowSize, hopSize, windowFunction, fftSize=None):
+    """gccNMF/gccNMFFunctions.py:61-67.  Like the reference, ``windowFunction`` is ignored
+    (numpy.hanning is hard-coded at :65), ``windowSize`` is the FFT length and ``fftSize`` the
+    window length.  Returns (2, F, T) complex64.  Both channels share one packed complex FFT."""
+    if fftSize is None:
+        fftSize = windowSize
+    from .librosaSTFT import _stft_device
+    chans = [np.squeeze(stereoSamples[c]).copy() for c in range(2)]
+    X = _stft_device(chans[0], chans[1], windowSize, hopSize, fftSize, hanning, center=False)
+    return X.astype(complex64)
+
+
+def performKLNMF(V, dictionarySize, numIterations, sparsityAlpha, epsilon=1e-16, seedValue=0):
+    """gccNMF/gccNMFFunctions.py:69-83.  The initial W, H come from NumPy's GLOBAL legacy
+    MT19937 exactly as in the reference (seed(seedValue); W first; :70-73) -- including the
+    side effect on the global RNG state; the iteration loop (:75-81) runs on the GPU."""
+    V = np.asarray(V)
+    F, N = V.shape
+    K = int(dictionarySize)
+    seed(seedValue)
+    W = random((F, K)).astype(float32) + epsilon
+    H = random((K, N)).astype(float32) + epsilon
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, 1, K)
+    Np = -(-N // 64) * 64
+    dV = padded(V.astype(float32), (g.Fp, Np), dev)
+    dW = padded(W.astype(float32), (g.Fp, g.Kp), dev)
+    dH = padded(H.astype(float32), (g.Kp, Np), dev)
+    ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, 1), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_klnmf(_ptr(dV), _ptr(dW), _ptr(dH), _ptr(ws), F, N, K, 1, int(numIterations),
+                                float(sparsityAlpha), float(epsilon), 0, _stream()), 'gccnmf_klnmf')
+    return dW[:F, :K].cpu().numpy(), dH[:K, :N].cpu().numpy()
+
+
+def _upload_coherence(C, g, dev):
+    C = np.asarray(C)
+    planes = np.stack([C.real, C.imag]).astype(float32)
+    return padded(planes, (2, g.Fp, g.Tp), dev)
+
+
+def getAngularSpectrogram(spectralCoherenceV, frequenciesInHz, microphoneSeparationInMetres, numTDOAs):
+    """gccNMF/gccNMFFunctions.py:85-92.  Returns (numTDOAs, T) float64 like the reference; the
+    contraction itself is an f32 MFMA GEMM [cos;sin]^T.[Re C;Im C]."""
+    F, T = spectralCoherenceV.shape
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, T, 1, int(numTDOAs))
+    trig = torch.from_numpy(steering_tables(frequenciesInHz, getTDOAsInSeconds(microphoneSeparationInMetres, numTDOAs),
+                                            g.Fp, g.Dp)).to(dev)
+    dC = _upload_coherence(spectralCoherenceV, g, dev)
+    ang = torch.zeros((g.Dp, g.Tp), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_angular_spectrogram(_ptr(dC), _ptr(trig), F, T, g.D, 1, _ptr(ang), 0, _stream()),
+               'gccnmf_angular_spectrogram')
+    return ang[:g.D, :T].cpu().numpy().astype(np.float64)
+
+
+def estimateTargetTDOAIndexesFromAngularSpectrum(angularSpectrum, microphoneSeparationInMetres, numTDOAs, numSources):
+    """gccNMF/gccNMFFunctions.py:94-116: strict local maxima, top ``numSources`` by value, sorted
+    ascending.  The reference's failure branches are NameErrors (:104 ``os``, :106 ``KMeans``);
+    here they raise ValueError."""
+    if not numSources:
+        raise ValueError('numSources is required (the reference KMeans branch cannot run: gccNMFFunctions.py:106)')
+    spectrum = np.ascontiguousarray(angularSpectrum, dtype=np.float64)
+    D = spectrum.shape[0]
+    lib, dev = _hip.lib(), _device()
+    logging.info('numSources provided, taking first %d peaks' % numSources)
+    dM = torch.from_numpy(spectrum).to(dev)
+    idx = torch.zeros((int(numSources),), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _hip.check(lib.gccnmf_pick_tdoa_peaks(_ptr(dM), D, D, int(numSources), 1, _ptr(idx), _ptr(status), _stream()),
+               'gccnmf_pick_tdoa_peaks')
+    if int(status.cpu()[0]) != 0:
+        raise ValueError("didn't find enough peaks in estimateTargetTDOAIndexesFromAngularSpectrum")
+    sourcePeakIndexes = sorted(np.int64(i) for i in idx.cpu().numpy())
+    logging.info('Found target TDOAs: %s' % str(sourcePeakIndexes))
+    return sourcePeakIndexes
+
+
+def getTargetTDOAGCCNMFs(coherenceV, microphoneSeparationInMetres, numTDOAs, frequenciesInHz, targetTDOAIndexes, W, stereoH):
+    """gccNMF/gccNMFFunctions.py:118-135.  Returns (numTargets, K, T) float32."""
+    numTargets = len(targetTDOAIndexes)
+    F, T = coherenceV.shape
+    numChannels, K, numTime = stereoH.shape
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, T, K, int(numTDOAs), numTargets)
+    trig = torch.from_numpy(steering_tables(frequenciesInHz, getTDOAsInSeconds(microphoneSeparationInMetres, numTDOAs),
+                                            g.Fp, g.Dp)).to(dev)
+    dC = _upload_coherence(coherenceV, g, dev)
+    dW = padded(np.asarray(W, dtype=float32), (g.Fp, g.Kp), dev)
+    dIdx = torch.tensor([int(i) for i in targetTDOAIndexes], dtype=torch.int32, device=dev)
+    ws = torch.zeros(lib.gccnmf_scores_workspace_floats(F, T, numTargets, 1), dtype=torch.float32, device=dev)
+    scores = torch.zeros((g.Kp, numTargets, g.Tp), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_target_scores_masks(_ptr(dC), _ptr(trig), _ptr(dIdx), _ptr(dW), F, T, K, g.D, numTargets, 1,
+                                              _ptr(ws), _ptr(scores), 0, _stream()), 'gccnmf_target_scores_masks')
+    return scores[:K, :, :T].permute(1, 0, 2).contiguous().cpu().numpy()
+
+
+def getTargetCoefficientMasks(targetTDOAGCCNMFs, numTargets):
+    """gccNMF/gccNMFFunctions.py:137-143: one-hot of nanargmax over targets (first wins ties);
+    only the first ``numTargets`` masks are filled, as in the reference loop."""
+    G = np.asarray(targetTDOAGCCNMFs)
+    if np.isnan(G).all(axis=0).any():
+        raise ValueError('All-NaN slice encountered')          # numpy.nanargmax behaviour (:138)
+    S, K, T = G.shape
+    am = _argmax_device(G)
+    masks = zeros_like(G)
+    for targetIndex in range(numTargets):
+        masks[targetIndex][where(am == targetIndex)] = 1
+    return masks
+
+
+def _argmax_device(G):
+    from .engine import _ptr as p
+    S, K, T = G.shape
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(2, T, K, 1, S)
+    scores = torch.zeros((g.Kp, S, g.Tp), dtype=torch.float32, device=dev)
+    scores[:K, :, :T] = torch.from_numpy(np.ascontiguousarray(G.astype(float32).transpose(1, 0, 2))).to(dev)
+    am = torch.zeros((g.Kp, g.Tp), dtype=torch.uint8, device=dev)
+    _hip.check(lib.gccnmf_argmax_targets(p(scores), K, T, S, 1, p(am), _stream()), 'gccnmf_argmax_targets')
+    return am[:K, :T].cpu().numpy()
+
+
+def getTargetSpectrogramEstimates(targetCoefficientMasks, complexMixtureSpectrogram, W, stereoH):
+    """gccNMF/gccNMFFunctions.py:145-151.  Returns (numTargets, 2, F, T) complex64."""
+    M = np.asarray(targetCoefficientMasks, dtype=float32)
+    X = np.asarray(complexMixtureSpectrogram)
+    S, K, T = M.shape
+    C, F, _ = X.shape
+    if C != 2:
+        raise ValueError('stereo spectrogram expected')
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, T, K, 1, S)
+    dM = padded(M, (S, g.Kp, g.Tp), dev)
+    dW = padded(np.asarray(W, dtype=float32), (g.Fp, g.Kp), dev)
+    H = np.concatenate([np.asarray(stereoH[c], dtype=float32) for c in range(2)], axis=-1)     # (K, 2T)
+    dH = padded(H, (g.Kp, g.Np), dev)
+    Xc = X.astype(complex64)
+    dX = padded(np.ascontiguousarray(Xc).view(float32).reshape(2, F, T, 2), (2, g.Fp, g.Tp, 2), dev)
+    dV = padded(np.concatenate(np.abs(Xc), axis=-1), (g.Fp, g.Np), dev)
+    ws = torch.zeros(lib.gccnmf_reconstruct_workspace_floats(T, K, S, 1), dtype=torch.float32, device=dev)
+    spec = torch.zeros((2 * S, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_reconstruct(_ptr(dW), _ptr(dH), 0, _ptr(dM), _ptr(dX), _ptr(dV), F, T, K, S, 1, _ptr(ws),
+                                      _ptr(spec), _stream()), 'gccnmf_reconstruct')
+    out = torch.view_as_complex(spec)[:, :F, :T].cpu().numpy()
+    return out.reshape(S, 2, F, T)
+
+
+def getTargetSignalEstimates(targetSpectrogramEstimates, windowSize, hopSize, windowFunction):
+    """gccNMF/gccNMFFunctions.py:153-163: istft (center=True) of every (target, channel) times
+    2*hop/ws.  Returns ndarray (numTargets, numChannels, hop*(T-1)) float32."""
+    S4 = np.asarray(targetSpectrogramEstimates)
+    numTargets, numChannels, numFreq, numTime = S4.shape
+    stftGainFactor = hopSize / float(windowSize) * 2
+    y = _istft_device(S4.reshape(numTargets * numChannels, numFreq, numTime), hopSize, windowSize, windowFunction,
+                      center=True, gain=stftGainFactor)
+    return y.reshape(numTargets, numChannels, -1)
+
+
+def saveTargetSignalEstimates(targetSignalEstimates, sampleRate, mixtureFileNamePrefix):
+    """gccNMF/gccNMFFunctions.py:165-169."""
+    numTargets = targetSignalEstimates.shape[0]
+    for targetIndex in range(numTargets):
+        wavwrite(targetSignalEstimates[targetIndex], getSourceEstimateFileName(mixtureFileNamePrefix, targetIndex), sampleRate)
+
+
+# ---- named by BASELINE.json's north_star; not in the reference -----------------
+def getTargetTDOAEstimates(complexMixtureSpectrogram, sampleRate, microphoneSeparationInMetres, numTDOAs, numSources):
+    """Convenience wrapper over the reference's three-step TDOA estimation
+    (runGCCNMF.py:44-47): coherence -> getAngularSpectrogram -> time mean ->
+    estimateTargetTDOAIndexesFromAngularSpectrum.  Returns (targetTDOAIndexes, meanAngularSpectrum)."""
+    X = np.asarray(complexMixtureSpectrogram).astype(complex64)
+    C, F, T = X.shape
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, T, 1, int(numTDOAs), int(numSources))
+    frequenciesInHz = linspace(0, sampleRate / 2.0, F)
+    trig = torch.from_numpy(steering_tables(frequenciesInHz, getTDOAsInSeconds(microphoneSeparationInMetres, numTDOAs),
+                                            g.Fp, g.Dp)).to(dev)
+    dX = padded(np.ascontiguousarray(X).view(float32).reshape(2, F, T, 2), (2, g.Fp, g.Tp, 2), dev)
+    dC = torch.zeros((2, g.Fp, g.Tp), dtype=torch.float32, device=dev)
+    ang = torch.zeros((g.Dp, g.Tp), dtype=torch.float32, device=dev)
+    meanA = torch.zeros((g.Dp,), dtype=torch.float64, device=dev)
+    idx = torch.zeros((g.S,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _hip.check(lib.gccnmf_coherence(_ptr(dX), F, T, 1, _ptr(dC), _stream()), 'gccnmf_coherence')
+    _hip.check(lib.gccnmf_angular_spectrogram(_ptr(dC), _ptr(trig), F, T, g.D, 1, _ptr(ang), _ptr(meanA), _stream()),
+               'gccnmf_angular_spectrogram')
+    _hip.check(lib.gccnmf_pick_tdoa_peaks(_ptr(meanA), g.D, g.Dp, g.S, 1, _ptr(idx), _ptr(status), _stream()),
+               'gccnmf_pick_tdoa_peaks')
+    if int(status.cpu()[0]) != 0:
+        raise ValueError("didn't find enough peaks in getTargetTDOAEstimates")
+    return sorted(np.int64(i) for i in idx.cpu().numpy()), meanA[:g.D].cpu().numpy()

@@ -1,0 +1,156 @@
+"""stft / istft with the call signatures of the reference's vendored librosa
+(gccNMF/librosaSTFT.py:20-286), computed by the HIP kernels in csrc/fft.hip.
+
+Argument validation and error types mirror the reference (ParameterError for
+non-contiguous / non-finite / too-short audio, bad hop, window-size mismatch);
+the transform itself has no CPU implementation here.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+from .engine import Geometry, padded, fft_twiddles, _ptr, _stream, num_frames
+
+
+class LibrosaError(Exception):
+    """gccNMF/librosaSTFT.py:288-290."""
+
+
+class ParameterError(LibrosaError):
+    """gccNMF/librosaSTFT.py:293-295."""
+
+
+def pad_center(data, size, axis=-1, **kwargs):
+    """gccNMF/librosaSTFT.py:297-368."""
+    kwargs.setdefault('mode', 'constant')
+    n = data.shape[axis]
+    lpad = int((size - n) // 2)
+    lengths = [(0, 0)] * data.ndim
+    lengths[axis] = (lpad, size - n - lpad)
+    if lpad < 0:
+        raise ParameterError('Target size ({:d}) must be at least input size ({:d})'.format(size, n))
+    return np.pad(data, lengths, **kwargs)
+
+
+def valid_audio(y, mono=False):
+    """gccNMF/librosaSTFT.py:437-491."""
+    if not isinstance(y, np.ndarray):
+        raise ParameterError('data must be of type numpy.ndarray')
+    if mono and y.ndim != 1:
+        raise ParameterError('Invalid shape for monophonic audio: ndim={:d}, shape={}'.format(y.ndim, y.shape))
+    elif y.ndim > 2:
+        raise ParameterError('Invalid shape for audio: ndim={:d}, shape={}'.format(y.ndim, y.shape))
+    if not np.isfinite(y).all():
+        raise ParameterError('Audio buffer is not finite everywhere')
+    return True
+
+
+def _window_vector(window, win_length, n_fft, inverse=False):
+    """gccNMF/librosaSTFT.py:133-151 (stft) / :251-270 (istft)."""
+    if window is None:
+        # reference default: scipy.signal.hann(win_length, sym=False) [* 2/3 for istft] (:135, :254)
+        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_length) / win_length)
+        if inverse:
+            w = w * (2.0 / 3)
+    elif callable(window):
+        w = window(win_length)
+    else:
+        w = np.asarray(window)
+        if w.size != n_fft:
+            raise ParameterError('Size mismatch between n_fft and len(window)' if not inverse
+                                 else 'Size mismatch between n_fft and window size')
+    return pad_center(w, n_fft)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _hip.HipLibraryError('no ROCm device visible: gcc_nmf_amd has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _check_frames(y, n_fft, hop_length):
+    """gccNMF/librosaSTFT.py:416-430 (frame())."""
+    if hop_length < 1:
+        raise ParameterError('Invalid hop_length: {:d}'.format(hop_length))
+    if not y.flags['C_CONTIGUOUS']:
+        raise ParameterError('Input buffer must be contiguous.')
+    valid_audio(y)
+    T = num_frames(len(y), n_fft, hop_length)
+    if T < 1:
+        raise ParameterError('Buffer is too short (n={:d}) for frame_length={:d}'.format(len(y), n_fft))
+    return T
+
+
+def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
+    """One packed complex FFT per frame carries both real signals (y1 may be None)."""
+    w = _window_vector(window, win_length, n_fft)
+    chans = []
+    for y in (y0, y1):
+        if y is None:
+            continue
+        if center:
+            valid_audio(y)
+            y = np.pad(y, int(n_fft // 2), mode='reflect')
+        chans.append(y)
+    T = None
+    for y in chans:
+        Tc = _check_frames(y, n_fft, hop_length)
+        if T is not None and Tc != T:
+            raise ParameterError('channels of different length')
+        T = Tc
+    n = len(chans[0])
+    lib, dev = _hip.lib(), _device()
+    F = n_fft // 2 + 1
+    g = Geometry(F, T, 1)
+    x = torch.zeros((2, n), dtype=torch.float32, device=dev)
+    for c, y in enumerate(chans):
+        x[c] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
+    dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
+    dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
+    X = torch.zeros((2, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_stft_stereo(_ptr(x), 2 * n, n, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), _ptr(X), 0, 0,
+                                      _stream()), 'gccnmf_stft_stereo')
+    out = torch.view_as_complex(X)[:, :F, :T].cpu().numpy()
+    return out if y1 is not None else out[0]
+
+
+def stft(y, n_fft=2048, hop_length=None, win_length=None, window=None, center=True, dtype=np.complex64):
+    """gccNMF/librosaSTFT.py:20-181.  Returns (1 + n_fft/2, T), Fortran-ordered like the reference."""
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length / 4)
+    return np.asfortranarray(_stft_device(y, None, n_fft, hop_length, win_length, window, center).astype(dtype))
+
+
+def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
+    """specs: (nsig, F, T) complex -> (nsig, L) float32."""
+    specs = np.asarray(specs)
+    nsig, F, T = specs.shape
+    n_fft = 2 * (F - 1)
+    w = _window_vector(window, win_length, n_fft, inverse=True)
+    lib, dev = _hip.lib(), _device()
+    g = Geometry(F, T, 1)
+    npad = nsig + (nsig & 1)
+    host = np.ascontiguousarray(specs.astype(np.complex64)).view(np.float32).reshape(nsig, F, T, 2)
+    dS = padded(host, (npad, g.Fp, g.Tp, 2), dev)
+    dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
+    dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
+    frames = torch.zeros((npad, T, n_fft), dtype=torch.float32, device=dev)
+    L = n_fft + hop_length * (T - 1) - (n_fft if center else 0)
+    if L < 1:
+        return np.zeros((nsig, 0), np.float32)
+    y = torch.zeros((npad, L), dtype=torch.float32, device=dev)
+    _hip.check(lib.gccnmf_istft_ola(_ptr(dS), npad, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), np.float32(gain),
+                                    1 if center else 0, _ptr(frames), _ptr(y), _stream()), 'gccnmf_istft_ola')
+    return y[:nsig].cpu().numpy()
+
+
+def istft(stft_matrix, hop_length=None, win_length=None, window=None, center=True, dtype=np.float32):
+    """gccNMF/librosaSTFT.py:183-286."""
+    n_fft = 2 * (stft_matrix.shape[0] - 1)
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length / 4)
+    return _istft_device(np.asarray(stft_matrix)[None], hop_length, win_length, window, center)[0].astype(dtype)

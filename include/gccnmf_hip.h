@@ -1,0 +1,151 @@
+/* libgccnmf_hip.so -- C ABI of the MI355X (gfx950) GCC-NMF hot path.
+ *
+ * The reference (seanwood/gcc-nmf) is pure Python/NumPy and has no FFI; its "operator API" for
+ * this path is the set of free functions in gccNMF/gccNMFFunctions.py + gccNMF/librosaSTFT.py.
+ * Each entry point below states which of those functions (file:line in the reference checkout)
+ * it computes.  gcc_nmf_amd/_hip.py is the ctypes binding; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM), every call is asynchronous on `stream`
+ *    (a hipStream_t passed as void*), every function returns a status code (0 = GCCNMF_OK);
+ *    nothing throws across this boundary;
+ *  - a "batch" is `batch` independent stereo mixture files of identical shape, laid out
+ *    back to back with the per-file strides implied by the padded geometry below;
+ *  - matrices are row-major float32 with padded pitches (gccnmf_pitches): padding is zero
+ *    on entry and stays zero.  Complex data is interleaved (re, im) float32 pairs.
+ *
+ * Geometry (F = n_fft/2+1 bins, T frames, N = 2T NMF columns, K atoms, D TDOAs, S targets):
+ *   Fp = round_up(F,16)  Kp = round_up(K,64)  Np = round_up(2T,64)  Tp = round_up(T,64)
+ *   X  [batch][2][Fp][Tp] complex   complexMixtureSpectrogram   (gccNMFFunctions.py:61-67)
+ *   V  [batch][Fp][Np]              concatenate(abs(X), -1)     (runGCCNMF.py:40)
+ *   CC [batch][2][Fp][Tp]           Re / Im planes of the PHAT coherence (runGCCNMF.py:44)
+ *   W  [batch][Fp][Kp]   H [batch][Kp][Np]                      (gccNMFFunctions.py:69-83)
+ */
+#ifndef GCCNMF_HIP_H
+#define GCCNMF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCCNMF_OK 0
+#define GCCNMF_ERR_ARG 1
+#define GCCNMF_ERR_LAUNCH 2
+#define GCCNMF_ERR_UNSUPPORTED 3
+
+/* flags for gccnmf_klnmf */
+#define GCCNMF_FLAG_NO_XCD_AFFINITY 1   /* plain file-major block order instead of the XCD-affine map */
+
+int gccnmf_version(void);
+
+/* Padded geometry every other entry point assumes. */
+int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
+
+/* Stereo STFT + magnitude + PHAT coherence, one launch for the whole batch.
+ * Replaces computeComplexMixtureSpectrogram (gccNMFFunctions.py:61-67 -> librosaSTFT.py:126-181,
+ * center=False, result conjugated), V = concatenate(abs(X)) (runGCCNMF.py:40) and
+ * spectralCoherenceV (runGCCNMF.py:44).
+ *   x        [batch][2][n_samples] float32 (file stride x_stride floats)
+ *   window   [n_fft] float32 analysis window (numpy.hanning(n_fft) for the reference path)
+ *   twiddle  [n_fft/2] complex: exp(-2j*pi*k/n_fft), computed in float64 on the host
+ *   X, V, CC as in the geometry table; V or CC may be NULL to skip that output. */
+int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
+                       const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
+
+/* KL-NMF multiplicative updates, independent dictionary per file.
+ * Replaces the iteration loop of performKLNMF (gccNMFFunctions.py:75-81); the MT19937 initial
+ * W, H (:70-73) are drawn on the host and passed in.  W and H are updated in place.
+ *   V [batch][Fp][Np], W [batch][Fp][Kp], H [batch][Kp][Np] with Np = round_up(N,64); N = 2T on the
+ *   GCC-NMF path but any N >= 1 is accepted (performKLNMF is also called on arbitrary V).
+ *   workspace: gccnmf_klnmf_workspace_floats(...) floats of scratch (R, R.H^T, K-vectors). */
+long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch);
+int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
+                 int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
+
+/* One launch group of the iteration on its own (per-kernel tests and per-kernel timing in bench.py).
+ * stage: 0 prepare (zero R, colsum W, scale = 1) | 1 R=V/(W.(s*H)) | 2 H update | 3 R=V/(W.H) |
+ *        4 U=R.H^T + rowsum H | 5 W update + atom normalisation | 6 materialise H *= s */
+int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
+                       float sparsity_alpha, float epsilon, int flags, int stage, void* stream);
+
+/* Shared-dictionary KL-NMF building blocks (one W for all files / all ranks; the host all-reduces
+ * `partial` across ranks between the two calls -- realtime/gccNMFPretraining.py:79-80 is the
+ * reference use of performKLNMF on one big V).
+ *   step A: H update with the current W, then partial[0:Fp*Kp] = sum_files (V/WH).H^T and
+ *           partial[Fp*Kp : Fp*Kp+Kp] = sum_files rowsum(H)   (deterministic file-order sum)
+ *   step B: W *= num/den, atom normalisation, and the compensating H rescale (applied lazily
+ *           through `workspace`; gccnmf_klnmf_shared_finish materialises it). */
+long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch);
+long gccnmf_klnmf_shared_partial_floats(int F, int K);
+int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, int K, int batch, void* stream);
+int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* workspace, float* partial, int F,
+                               int N, int K, int batch, float sparsity_alpha, float epsilon, void* stream);
+int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch,
+                               void* stream);
+int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream);
+
+/* GCC-PHAT angular spectrogram A[tau][t] = sum_f Re(C[f,t] exp(-2j pi f tau)) as a real GEMM
+ * [cos;sin]^T . [Re C; Im C], plus its time mean.  Replaces getAngularSpectrogram
+ * (gccNMFFunctions.py:85-92) and mean(.., axis=-1) (runGCCNMF.py:46).
+ *   trig   [2][Fp][Dp] float32: cos(2 pi f tau) / sin(2 pi f tau), Dp = round_up(D,64), zero padded
+ *   ang    [batch][Dp][Tp] float32 out,  mean_ang [batch][Dp] float64 out (may be NULL) */
+int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T, int D, int batch, float* ang,
+                               double* mean_ang, void* stream);
+
+/* Peak picking on the mean angular spectrum: strict local maxima (edges excluded), keep the
+ * S largest, ascending order.  Replaces estimateTargetTDOAIndexesFromAngularSpectrum
+ * (gccNMFFunctions.py:94-116) for numSources > 0.
+ *   tdoa_idx [batch][S] int32 out; status [batch] int32 out (0 ok, 1 = fewer than S peaks) */
+int gccnmf_pick_tdoa_peaks(const double* mean_ang, int D, int Dp, int S, int batch, int* tdoa_idx, int* status,
+                           void* stream);
+
+/* Per-target GCC-NMF scores G_i[k,t] = Re sum_f W[f,k] C[f,t] exp(-2j pi f tau_i) and the
+ * arg-max-over-targets coefficient mask (first index wins ties, NaN ignored).  Replaces
+ * getTargetTDOAGCCNMFs (gccNMFFunctions.py:118-135) + getTargetCoefficientMasks (:137-143).
+ *   tdoa_idx [batch][S] device int32 (from gccnmf_pick_tdoa_peaks or uploaded)
+ *   scores   [batch][Kp][S*Tp] float32 out (target i occupies columns i*Tp .. i*Tp+T-1)
+ *   argmax   [batch][Kp][Tp] uint8 out;  workspace: gccnmf_scores_workspace_floats floats */
+long gccnmf_scores_workspace_floats(int F, int T, int S, int batch);
+int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* tdoa_idx, const float* W, int F,
+                               int T, int K, int D, int S, int batch, float* workspace, float* scores,
+                               unsigned char* argmax, void* stream);
+
+/* The arg-max half of the call above on its own (host-array getTargetCoefficientMasks,
+ * gccNMFFunctions.py:137-143): scores [batch][Kp][S*Tp] -> argmax [batch][Kp][Tp]. */
+int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, unsigned char* argmax, void* stream);
+
+/* PHAT coherence from an existing spectrogram X [batch][2][Fp][Tp] (runGCCNMF.py:44); the pipeline
+ * gets CC from gccnmf_stft_stereo's epilogue instead. */
+int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* stream);
+
+/* Masked reconstruction S[i,c] = (W . (H_c * M_i)) * X_c/|X_c|.  Replaces
+ * getTargetSpectrogramEstimates (gccNMFFunctions.py:145-151).
+ *   the mask is either `argmax` [batch][Kp][Tp] uint8 (one-hot masks, the device pipeline) or, when
+ *   `masks` != NULL, arbitrary float masks [batch][S][Kp][Tp] (the reference signature accepts any array)
+ *   spec [batch][S*2][Fp][Tp] complex out (index i*2+c); workspace: gccnmf_reconstruct_workspace_floats */
+long gccnmf_reconstruct_workspace_floats(int T, int K, int S, int batch);
+int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argmax, const float* masks,
+                       const float* X, const float* V, int F, int T, int K, int S, int batch, float* workspace,
+                       float* spec, void* stream);
+
+/* Inverse STFT + overlap-add + centre trim + gain for `nsig` spectrograms per file.  Replaces
+ * getTargetSignalEstimates (gccNMFFunctions.py:153-163 -> librosaSTFT.py:241-286, center=True).
+ *   spec   [batch][nsig][Fp][Tp] complex (nsig must be even: signals are inverse-transformed in pairs)
+ *   window [n_fft] synthesis window; twiddle as for the forward transform
+ *   frames [batch][nsig][T][n_fft] float32 scratch
+ *   center != 0 trims n_fft/2 samples at both ends (the reference path), 0 keeps all n_fft + hop*(T-1)
+ *   y      [batch][nsig][L] float32 out, L = n_fft + hop*(T-1) - (center ? n_fft : 0) */
+int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
+                     const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
+
+/* Diagnostics (tests only): run one MFMA GEMM configuration in isolation.
+ * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid. */
+int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc,
+                      int a_clamp, int b_clamp, int layout, int batch, long sA, long sB, long sC,
+                      const float* bscale, float* rowsumB, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

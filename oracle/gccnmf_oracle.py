@@ -305,27 +305,7 @@ def runGCCNMF(stereoSamples, sampleRate, windowSize, hopSize, numTDOAs, micropho
 
 
 # --------------------------------------------------------------------------
-# synthetic mixtures (SURVEY.md 8d recipe) -- shared by tests and bench
+# synthetic mixtures (SURVEY.md 8d recipe): the generator lives with the product's input
+# tooling; re-exported here so that tests / make_golden.py have one name for it
 # --------------------------------------------------------------------------
-def synthetic_mixture(fileIndex, numSamples=160000, sampleRate=16000, delays=(-20, 3, 27)):
-    """three low-passed, slowly modulated noise
-    sources; right channel = integer-sample delayed copies; sensor noise floor so
-    that |X| > 0 everywhere (no NaN coherence); int16-representable float32."""
-    from scipy.signal import butter, lfilter
-    rng = np.random.default_rng(20260925 + fileIndex)
-    t = np.arange(numSamples) / float(sampleRate)
-    b, a = butter(4, 4000.0 / (sampleRate / 2.0))
-    left = np.zeros(numSamples)
-    right = np.zeros(numSamples)
-    for j, d in enumerate(delays):
-        s = lfilter(b, a, rng.standard_normal(numSamples))
-        phi = rng.uniform(0, 2 * np.pi)
-        s = s * 0.5 * (1 + np.sin(2 * np.pi * (0.7 + 0.3 * j) * t + phi))
-        left += s
-        right += np.roll(s, d)
-    left += rng.normal(0, 1e-3, numSamples)
-    right += rng.normal(0, 1e-3, numSamples)
-    x = np.stack([left, right])
-    x = x / np.max(np.abs(x)) * 0.1
-    pcm = np.round(x * 32768).astype(np.int16)
-    return pcm2float(pcm).astype(np.float32)
+from gcc_nmf_amd.synthetic import synthetic_mixture    # noqa: E402,F401

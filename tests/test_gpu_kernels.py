@@ -1,0 +1,328 @@
+"""-m gpu: every HIP kernel against the CPU oracle, called through the C ABI (ctypes).
+
+Tolerances (SURVEY.md 8c / BASELINE.json north_star): integer outputs (TDOA indexes, arg-max
+masks away from exact ties) bit-exact; f32 GEMM / FFT results within f32 round-off of the
+float64 oracle; W,H rel-Frobenius <= 1e-4; waveforms RMS <= 1e-4.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import gccnmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from gcc_nmf_amd import _hip
+    assert torch.cuda.is_available(), 'the gpu tests need a ROCm device'
+    return _hip
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+# ------------------------------------------------------------------------------------------------
+# the MFMA GEMM template, every operand layout / wave grid / tail / batch mapping
+# ------------------------------------------------------------------------------------------------
+GEMM_CASES = [
+    # (layout bits, M, N, Kd, batch)   bits: 1 A_KC, 2 B_KC, 4 tail row, 8 wide <1,4> grid
+    (0, 300, 200, 100, 1), (0 | 8, 100, 300, 37, 2), (0, 1024, 130, 513, 9),
+    (1, 200, 150, 64, 1), (1 | 4, 513, 200, 100, 3), (1 | 4, 513, 1244, 128, 9), (1 | 8, 128, 300, 48, 2),
+    (1 | 4 | 8, 129, 260, 40, 1),
+    (3, 200, 64, 150, 1), (3 | 4, 513, 128, 300, 2), (3 | 4, 513, 200, 1244, 8), (3 | 8, 100, 256, 75, 1),
+    (3 | 4 | 8, 129, 300, 50, 2),
+]
+
+
+@pytest.mark.parametrize('layout,M,N,Kd,batch', GEMM_CASES)
+def test_debug_gemm(hip, layout, M, N, Kd, batch):
+    lib = hip.lib()
+    rng = np.random.RandomState(layout * 1000 + M + N + Kd)
+    a_kc, b_kc = bool(layout & 1), bool(layout & 2)
+    Kd16 = -(-Kd // 16) * 16
+    A = rng.standard_normal((batch, M, Kd)).astype(np.float32)          # asymmetric, signed
+    B = (rng.standard_normal((batch, Kd, N)) + 0.5).astype(np.float32)
+    # padded device images (reduction padding must be zero)
+    if a_kc:
+        lda, a_rows = Kd16, M
+        Ad = np.zeros((batch, a_rows, lda), np.float32)
+        Ad[:, :, :Kd] = A
+        a_clamp = a_rows - 1
+    else:
+        lda, a_rows = -(-M // 4) * 4, Kd16
+        Ad = np.zeros((batch, a_rows, lda), np.float32)
+        Ad[:, :Kd, :M] = A.transpose(0, 2, 1)
+        a_clamp = lda - 4
+    if b_kc:
+        ldb, b_rows = Kd16, N
+        Bd = np.zeros((batch, b_rows, ldb), np.float32)
+        Bd[:, :, :Kd] = B.transpose(0, 2, 1)
+        b_clamp = b_rows - 1
+    else:
+        ldb, b_rows = -(-N // 4) * 4, Kd16
+        Bd = np.zeros((batch, b_rows, ldb), np.float32)
+        Bd[:, :Kd, :N] = B
+        b_clamp = ldb - 4
+    ldc = N + 3
+    dA, dB = dev(Ad), dev(Bd)
+    dC = torch.full((batch, M, ldc), -7.0, dtype=torch.float32, device='cuda')
+    bscale = None
+    dscale = None
+    if not b_kc:
+        bscale = (rng.rand(Kd16) + 0.5).astype(np.float32)
+        dscale = dev(bscale)
+    drow = torch.zeros((batch, N), dtype=torch.float32, device='cuda') if b_kc else None
+    rc = lib.gccnmf_debug_gemm(dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), M, N, Kd, lda, ldb, ldc, a_clamp, b_clamp, layout,
+                               batch, Ad[0].size, Bd[0].size, M * ldc, 0 if dscale is None else dscale.data_ptr(),
+                               0 if drow is None else drow.data_ptr(), stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    C = dC.cpu().numpy()
+    Bs = B.astype(np.float64)
+    if bscale is not None:
+        Bs = Bs * bscale[None, :Kd, None]
+    ref = np.einsum('bmk,bkn->bmn', A.astype(np.float64), Bs)
+    scale = np.abs(A).astype(np.float64).max() * np.abs(Bs).max() * Kd
+    err = np.abs(C[:, :, :N] - ref).max()
+    assert err < 2e-6 * scale, (err, scale)
+    assert np.all(C[:, :, N:] == -7.0), 'wrote outside the valid columns'
+    if drow is not None:
+        rs = drow.cpu().numpy()
+        assert np.abs(rs - B.sum(axis=1)).max() < 1e-4 * Kd
+
+
+# ------------------------------------------------------------------------------------------------
+# STFT / iSTFT
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_fft,hop,n', [(1024, 256, 20000), (1024, 128, 6000), (512, 64, 5000), (256, 100, 3000), (2048, 512, 9000)])
+def test_stft_stereo(hip, n_fft, hop, n):
+    from gcc_nmf_amd.gccNMFFunctions import computeComplexMixtureSpectrogram
+    rng = np.random.RandomState(n_fft + hop)
+    x = (rng.standard_normal((2, n)) * 0.1).astype(np.float32)
+    X = computeComplexMixtureSpectrogram(x, n_fft, hop, np.hanning)
+    ref = O.computeComplexMixtureSpectrogram(x, n_fft, hop, np.hanning)
+    assert X.shape == ref.shape and X.dtype == np.complex64
+    assert np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_stft_mono_center_and_errors(hip):
+    from gcc_nmf_amd.librosaSTFT import stft, istft, ParameterError
+    rng = np.random.RandomState(3)
+    y = (rng.standard_normal(7000) * 0.1).astype(np.float32)
+    for center in (False, True):
+        X = stft(y, 1024, 256, 1024, np.hanning, center=center)
+        ref = O.stft(y, 1024, 256, 1024, np.hanning, center=center)
+        assert X.shape == ref.shape and np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
+    with pytest.raises(ParameterError):
+        stft(np.zeros(100, np.float32), 1024, 256, 1024, np.hanning, center=False)
+    with pytest.raises(ParameterError):
+        stft(y, 1024, 0, 1024, np.hanning, center=False)
+    bad = y.copy()
+    bad[5] = np.nan
+    with pytest.raises(ParameterError):
+        stft(bad, 1024, 256, 1024, np.hanning, center=False)
+    with pytest.raises(ParameterError):
+        stft(np.zeros(9000, np.float32)[::2], 1024, 256, 1024, np.hanning, center=False)
+    with pytest.raises(ParameterError):
+        stft(y, 1024, 256, 1024, np.ones(1000), center=False)
+    spec = (rng.standard_normal((513, 9)) + 1j * rng.standard_normal((513, 9))).astype(np.complex64)
+    for center in (True, False):
+        yy = istft(spec, 256, 1024, np.hanning, center=center)
+        ref = O.istft(spec, 256, 1024, np.hanning, center=center)
+        assert yy.shape == ref.shape and yy.dtype == np.float32
+        assert np.abs(yy - ref).max() < 2e-6 * np.abs(ref).max()
+
+
+def test_stft_istft_golden_kat(hip):
+    from gcc_nmf_amd.librosaSTFT import stft, istft
+    kat = golden('kat_primitives')
+    for n_fft, hop in [(1024, 256), (1024, 128), (512, 64), (256, 100)]:
+        ref = kat['stft_%d_%d' % (n_fft, hop)]
+        X = stft(kat['stft_sig'].copy(), n_fft, hop, n_fft, np.hanning, center=False)
+        assert np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
+    for key, spec, hop, ws in [('istft_1024_256', 'istft_spec', 256, 1024), ('istft_1024_128', 'istft_spec', 128, 1024),
+                               ('istft_256_64', 'istft_spec2', 64, 256)]:
+        y = istft(kat[spec], hop, ws, np.hanning)
+        assert y.shape == kat[key].shape
+        assert np.abs(y - kat[key]).max() < 2e-6 * np.abs(kat[key]).max()
+
+
+def test_signal_estimates(hip):
+    from gcc_nmf_amd.gccNMFFunctions import getTargetSignalEstimates
+    rng = np.random.RandomState(11)
+    S = (rng.standard_normal((3, 2, 513, 40)) + 1j * rng.standard_normal((3, 2, 513, 40))).astype(np.complex64)
+    y = getTargetSignalEstimates(S, 1024, 256, np.hanning)
+    ref = O.getTargetSignalEstimates(S, 1024, 256, np.hanning)
+    assert y.shape == ref.shape == (3, 2, 256 * 39) and y.dtype == np.float32
+    assert np.abs(y - ref).max() < 2e-6 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# KL-NMF
+# ------------------------------------------------------------------------------------------------
+def test_klnmf_golden_kat(hip):
+    from gcc_nmf_amd.gccNMFFunctions import performKLNMF
+    kat = golden('kat_primitives')
+    for name in 'abc':
+        K, it, alpha = kat['nmf_%s_params' % name]
+        W, H = performKLNMF(kat['nmf_V'], int(K), int(it), alpha if alpha else 0)
+        assert W.dtype == np.float32 and W.shape == kat['nmf_%s_W' % name].shape
+        assert rel(W, kat['nmf_%s_W' % name]) < 1e-5 and rel(H, kat['nmf_%s_H' % name]) < 1e-5
+    W, H = performKLNMF(kat['nmf_V'], 4, 2, 0, seedValue=7)
+    assert rel(W, kat['nmf_seed7_W']) < 1e-5 and rel(H, kat['nmf_seed7_H']) < 1e-5
+
+
+@pytest.mark.parametrize('F,N,K,iters,alpha', [(513, 90, 128, 12, 0), (513, 201, 192, 6, 0.3), (257, 77, 40, 10, 0), (200, 333, 300, 5, 0),
+                                               (129, 64, 64, 8, 0), (1025, 50, 64, 4, 0)])
+def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha):
+    from gcc_nmf_amd.gccNMFFunctions import performKLNMF
+    rng = np.random.RandomState(F + N + K)
+    V = (np.abs(rng.standard_normal((F, N))) + 0.01).astype(np.float32)
+    state = np.random.get_state()
+    W, H = performKLNMF(V, K, iters, alpha)
+    Wr, Hr = O.performKLNMF(V, K, iters, alpha)
+    assert W.shape == (F, K) and H.shape == (K, N)
+    assert rel(W, Wr) < 1e-4 and rel(H, Hr) < 1e-4, (rel(W, Wr), rel(H, Hr))
+    # the reference leaves the global RNG seeded-and-advanced; so do we
+    np.random.seed(0)
+    np.random.random((F, K))
+    np.random.random((K, N))
+    expected_next = np.random.random()
+    performKLNMF(V, K, 0, 0)
+    assert np.random.random() == expected_next
+    np.random.set_state(state)
+
+
+def test_klnmf_batch_is_file_independent(hip):
+    """A file's result does not depend on the batch it rides in (XCD-affine map for batch >= 8 included)."""
+    lib = hip.lib()
+    F, T, K, B = 513, 30, 128, 9
+    N = 2 * T
+    rng = np.random.RandomState(5)
+    from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
+    g = Geometry(F, T, K)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    outs = []
+    for files in ([0], [8], list(range(B))):
+        b = len(files)
+        dV = padded(V[files], (b, g.Fp, g.Np), 'cuda')
+        dW = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
+        dH = padded(np.repeat(H0[None], b, 0), (b, g.Kp, g.Np), 'cuda')
+        ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, b), dtype=torch.float32, device='cuda')
+        assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, b, 5, 0.0, 1e-16, 0, stream()) == 0
+        outs.append((dW.cpu().numpy(), dH.cpu().numpy()))
+    assert np.array_equal(outs[0][0][0], outs[2][0][0]) and np.array_equal(outs[0][1][0], outs[2][1][0])
+    assert np.array_equal(outs[1][0][0], outs[2][0][8]) and np.array_equal(outs[1][1][0], outs[2][1][8])
+    # padding stayed zero
+    Wp, Hp = outs[2]
+    assert not Wp[:, F:, :].any() and not Wp[:, :, K:].any() and not Hp[:, K:, :].any() and not Hp[:, :, N:].any()
+    # and it matches the oracle
+    Wr, Hr = O.performKLNMF(V[8], K, 5, 0)
+    assert rel(Wp[8, :F, :K], Wr) < 1e-4 and rel(Hp[8, :K, :N], Hr) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# localisation, scores, masks, reconstruction
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def scene():
+    x = O.synthetic_mixture(1, numSamples=40000)
+    return O.runGCCNMF(x, 16000, 1024, 256, 128, 1.0, 3, dictionarySize=64, numIterations=15, return_intermediates=True), x
+
+
+def test_angular_spectrogram_and_peaks(hip, scene):
+    from gcc_nmf_amd import gccNMFFunctions as G
+    r, x = scene
+    freqs = np.linspace(0, 8000.0, 513)
+    A = G.getAngularSpectrogram(r['C'], freqs, 1.0, 128)
+    assert A.shape == r['A'].shape and A.dtype == np.float64
+    assert np.abs(A - r['A']).max() < 1e-3
+    idx = G.estimateTargetTDOAIndexesFromAngularSpectrum(np.mean(A, axis=-1), 1.0, 128, 3)
+    assert idx == r['idx'] and isinstance(idx, list)
+    idx2, meanA = G.getTargetTDOAEstimates(r['X'], 16000, 1.0, 128, 3)
+    assert idx2 == r['idx'] and np.abs(meanA - r['meanA']).max() < 1e-3
+    kat = golden('kat_primitives')
+    s = kat['peaks_spectrum']
+    assert G.estimateTargetTDOAIndexesFromAngularSpectrum(s, 1.0, len(s), 2) == list(kat['peaks_top2'])
+    assert G.estimateTargetTDOAIndexesFromAngularSpectrum(s, 1.0, len(s), 3) == list(kat['peaks_top3'])
+    with pytest.raises(ValueError):
+        G.estimateTargetTDOAIndexesFromAngularSpectrum(s, 1.0, len(s), 9)
+    with pytest.raises(ValueError):
+        G.estimateTargetTDOAIndexesFromAngularSpectrum(s, 1.0, len(s), None)
+
+
+def test_scores_masks_reconstruction(hip, scene):
+    from gcc_nmf_amd import gccNMFFunctions as G
+    r, x = scene
+    freqs = np.linspace(0, 8000.0, 513)
+    stereoH = np.array(np.hsplit(r['H'], 2))
+    Gs = G.getTargetTDOAGCCNMFs(r['C'], 1.0, 128, freqs, r['idx'], r['W'], stereoH)
+    assert Gs.shape == r['G'].shape and Gs.dtype == np.float32
+    assert np.abs(Gs - r['G']).max() < 2e-5 * np.abs(r['G']).max()
+    M = G.getTargetCoefficientMasks(r['G'], 3)
+    assert np.array_equal(M, r['M'])                                   # same scores in -> identical masks out
+    kat = golden('kat_primitives')
+    assert np.array_equal(G.getTargetCoefficientMasks(kat['masks_in'], 3), kat['masks_out'])   # tie + NaN cases
+    allnan = kat['masks_in'].copy()
+    allnan[:, 0, 0] = np.nan
+    with pytest.raises(ValueError):
+        G.getTargetCoefficientMasks(allnan, 3)
+    Sp = G.getTargetSpectrogramEstimates(r['M'], r['X'], r['W'], stereoH)
+    assert Sp.shape == r['S'].shape and Sp.dtype == np.complex64
+    assert np.abs(Sp - r['S']).max() < 1e-5 * np.abs(r['S']).max()
+    # soft masks go through the same entry point
+    soft = np.random.RandomState(2).rand(*r['M'].shape).astype(np.float32)
+    Sp2 = G.getTargetSpectrogramEstimates(soft, r['X'], r['W'], stereoH)
+    ref2 = O.getTargetSpectrogramEstimates(soft, r['X'], r['W'], stereoH)
+    assert np.abs(Sp2 - ref2).max() < 1e-5 * np.abs(ref2).max()
+
+
+def test_reference_call_sequence_dropin(hip, scene):
+    """gccNMF/runGCCNMF.py:36-52, line by line, on the replacement module's names."""
+    from gcc_nmf_amd.gccNMFFunctions import (computeComplexMixtureSpectrogram, performKLNMF, getAngularSpectrogram,
+                                            estimateTargetTDOAIndexesFromAngularSpectrum, getTargetTDOAGCCNMFs,
+                                            getTargetCoefficientMasks, getTargetSpectrogramEstimates, getTargetSignalEstimates,
+                                            hanning, linspace, concatenate, array, hsplit, mean)
+    r, stereoSamples = scene
+    sampleRate, windowSize, hopSize, numTDOAs, d, numTargets = 16000, 1024, 256, 128, 1.0, 3
+    complexMixtureSpectrogram = computeComplexMixtureSpectrogram(stereoSamples, windowSize, hopSize, hanning)
+    numChannels, numFrequencies, numTime = complexMixtureSpectrogram.shape
+    frequenciesInHz = linspace(0, sampleRate / 2.0, numFrequencies)
+    V = concatenate(abs(complexMixtureSpectrogram), axis=-1)
+    W, H = performKLNMF(V, dictionarySize=64, numIterations=15, sparsityAlpha=0)
+    stereoH = array(hsplit(H, numChannels))
+    spectralCoherenceV = complexMixtureSpectrogram[0] * complexMixtureSpectrogram[1].conj() / abs(complexMixtureSpectrogram[0]) / abs(complexMixtureSpectrogram[1])
+    angularSpectrogram = getAngularSpectrogram(spectralCoherenceV, frequenciesInHz, d, numTDOAs)
+    meanAngularSpectrum = mean(angularSpectrogram, axis=-1)
+    targetTDOAIndexes = estimateTargetTDOAIndexesFromAngularSpectrum(meanAngularSpectrum, d, numTDOAs, numTargets)
+    targetTDOAGCCNMFs = getTargetTDOAGCCNMFs(spectralCoherenceV, d, numTDOAs, frequenciesInHz, targetTDOAIndexes, W, stereoH)
+    targetCoefficientMasks = getTargetCoefficientMasks(targetTDOAGCCNMFs, numTargets)
+    targetSpectrogramEstimates = getTargetSpectrogramEstimates(targetCoefficientMasks, complexMixtureSpectrogram, W, stereoH)
+    targetSignalEstimates = getTargetSignalEstimates(targetSpectrogramEstimates, windowSize, hopSize, hanning)
+    assert targetTDOAIndexes == r['idx']
+    assert rel(W, r['W']) < 1e-4 and rel(H, r['H']) < 1e-4
+    assert np.mean(np.argmax(targetCoefficientMasks, 0) != np.argmax(r['M'], 0)) < 1e-3
+    assert targetSignalEstimates.shape == r['y'].shape and targetSignalEstimates.dtype == np.float32
+    rms = np.sqrt(np.mean((targetSignalEstimates.astype(np.float64) - r['y']) ** 2))
+    assert rms < 1e-4, rms

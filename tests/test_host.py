@@ -1,0 +1,133 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports exactly what include/gccnmf_hip.h
+declares, geometry helpers, wav conventions, the drop-in module's exported names, and that the product
+fails loudly (never falls back to the CPU) when no device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, golden
+
+HEADER = os.path.join(REPO, 'include', 'gccnmf_hip.h')
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|long)\s+(gccnmf_\w+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gcc_nmf_amd import _hip
+    names = declared_functions()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_hip.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), n
+    assert sorted(_hip.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert _hip.lib().gccnmf_version() >= 100
+
+
+def test_pitches_and_workspace_sizes():
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    v = [ctypes.c_int() for _ in range(4)]
+    assert lib.gccnmf_pitches(513, 622, 1024, *[ctypes.byref(x) for x in v]) == 0
+    assert [x.value for x in v] == [528, 1024, 1280, 640]
+    assert lib.gccnmf_pitches(513, 622, 128, *[ctypes.byref(x) for x in v]) == 0
+    assert [x.value for x in v] == [528, 128, 1280, 640]
+    assert lib.gccnmf_pitches(1, 622, 128, *[ctypes.byref(x) for x in v]) == 1           # GCCNMF_ERR_ARG
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == 528 * 1280 + 528 * 1024 + 3 * 1024
+    assert lib.gccnmf_klnmf_workspace_floats(513, 0, 1024, 1) == -1
+    # argument checking happens before any HIP call, so it is testable without a GPU
+    assert lib.gccnmf_klnmf(0, 0, 0, 0, 513, 1244, 1024, 1, 1, 0.0, 1e-16, 0, 0) == 1
+    assert lib.gccnmf_stft_stereo(0, 0, 0, 1000, 256, 1, 1, 0, 0, 0, 0, 0, 0) == 1
+    assert lib.gccnmf_istft_ola(0, 3, 1024, 256, 4, 1, 0, 0, 1.0, 1, 0, 0, 0) == 1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a device is present')
+    from gcc_nmf_amd import HipLibraryError
+    from gcc_nmf_amd import gccNMFFunctions as G
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    V = np.ones((5, 6), np.float32)
+    with pytest.raises(HipLibraryError):
+        G.performKLNMF(V, 2, 1, 0)
+    with pytest.raises(HipLibraryError):
+        G.computeComplexMixtureSpectrogram(np.zeros((2, 4096), np.float32), 1024, 256, np.hanning)
+    with pytest.raises(HipLibraryError):
+        GCCNMFEngine(16000)
+    import gcc_nmf_amd
+    src = ''.join(open(os.path.join(os.path.dirname(gcc_nmf_amd.__file__), f)).read()
+                  for f in os.listdir(os.path.dirname(gcc_nmf_amd.__file__)) if f.endswith('.py'))
+    assert 'import oracle' not in src and 'from oracle' not in src, 'the product must never import the oracle'
+
+
+def test_dropin_module_names():
+    """Everything the reference driver pulls out of `from gccNMFFunctions import *` (runGCCNMF.py:27-54)."""
+    from gcc_nmf_amd import gccNMFFunctions as G
+    for name in ['getMixtureFileName', 'getSourceEstimateFileName', 'loadMixtureSignal', 'getMaxTDOA', 'getTDOAsInSeconds',
+                 'getFrequenciesInHz', 'computeComplexMixtureSpectrogram', 'performKLNMF', 'getAngularSpectrogram',
+                 'estimateTargetTDOAIndexesFromAngularSpectrum', 'getTargetTDOAGCCNMFs', 'getTargetCoefficientMasks',
+                 'getTargetSpectrogramEstimates', 'getTargetSignalEstimates', 'saveTargetSignalEstimates',
+                 'getTargetTDOAEstimates', 'SPEED_OF_SOUND_IN_METRES_PER_SECOND', 'stft', 'istft', 'wavread', 'wavwrite',
+                 'hanning', 'linspace', 'float32', 'concatenate', 'array', 'hsplit', 'mean']:
+        assert hasattr(G, name), name
+    assert G.SPEED_OF_SOUND_IN_METRES_PER_SECOND == 340.29
+    assert G.getMixtureFileName('a/b') == 'a/b_mix.wav' and G.getSourceEstimateFileName('a/b', 1) == 'a/b_sim_2.wav'
+    kat = golden('kat_primitives')
+    assert np.array_equal(G.getTDOAsInSeconds(1.0, 128), kat['tdoas_128'])
+    assert np.array_equal(G.getFrequenciesInHz(16000, 513), kat['freqs_513'])
+    import inspect
+    sig = inspect.signature(G.performKLNMF)
+    assert list(sig.parameters) == ['V', 'dictionarySize', 'numIterations', 'sparsityAlpha', 'epsilon', 'seedValue']
+    assert sig.parameters['epsilon'].default == 1e-16 and sig.parameters['seedValue'].default == 0
+    assert list(inspect.signature(G.computeComplexMixtureSpectrogram).parameters) == \
+        ['stereoSamples', 'windowSize', 'hopSize', 'windowFunction', 'fftSize']
+    assert list(inspect.signature(G.getTargetTDOAGCCNMFs).parameters) == \
+        ['coherenceV', 'microphoneSeparationInMetres', 'numTDOAs', 'frequenciesInHz', 'targetTDOAIndexes', 'W', 'stereoH']
+
+
+def test_wav_conventions(tmp_path):
+    from gcc_nmf_amd import wavfile as Wf
+    kat = golden('kat_primitives')
+    assert np.array_equal(Wf.pcm2float(kat['pcm_in']), kat['pcm2float'])
+    assert np.array_equal(Wf.float2pcm(kat['float_in']), kat['float2pcm'])
+    with pytest.raises(TypeError):
+        Wf.pcm2float(np.zeros(3, np.float32))
+    with pytest.raises(TypeError):
+        Wf.float2pcm(np.zeros(3, np.int16))
+    x = (np.random.RandomState(0).rand(2, 1000).astype(np.float32) - 0.5) * 0.5
+    p = str(tmp_path / 'a.wav')
+    Wf.wavwrite(x, p, 16000)
+    y, sr = Wf.wavread(p)
+    assert sr == 16000 and y.shape == (2, 1000) and y.dtype == np.float32
+    assert np.abs(y - x).max() <= 1.0 / 32768
+    loud = x * 10
+    Wf.wavwrite(loud, p, 16000)                       # clip protection: rescaled to 0.99 peak
+    y, _ = Wf.wavread(p)
+    assert abs(np.abs(y).max() - 0.99) < 1e-3
+    with pytest.raises(ValueError):
+        Wf.wavwrite(loud, p, 16000, clipProtection=False)
+    ref, sr = Wf.wavread(os.path.join(REPO, 'tests', 'golden', 'data', 'dev1_female3_liverec_130ms_1m_mix.wav'))
+    assert ref.shape == (2, 160000) and sr == 16000 and ref.dtype == np.float32
+
+
+def test_constant_tables():
+    from gcc_nmf_amd.engine import fft_twiddles, steering_tables, klnmf_initial_factors, num_frames
+    from oracle import gccnmf_oracle as O
+    tw = fft_twiddles(1024).view(np.complex64)
+    assert tw.shape == (512,) and abs(tw[256] - (-1j)) < 1e-7 and tw[0] == 1
+    f, tau = np.linspace(0, 8000, 513), O.getTDOAsInSeconds(1.0, 128)
+    trig = steering_tables(f, tau, 528, 128)
+    E = np.exp(np.outer(f, -(2j * np.pi) * tau))
+    assert trig.shape == (2, 528, 128) and np.allclose(trig[0, :513], E.real, atol=1e-7) and np.allclose(trig[1, :513], -E.imag, atol=1e-7)
+    assert not trig[:, 513:].any()
+    W, H = klnmf_initial_factors(33, 50, 8)
+    Wr, Hr = O.initKLNMF(33, 50, 8)
+    assert np.array_equal(W, Wr) and np.array_equal(H, Hr) and W.dtype == np.float32
+    assert num_frames(160000, 1024, 256) == 622 and num_frames(160000, 1024, 128) == 1243
