@@ -97,10 +97,15 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
             Vb[T + t] = aR;
         }
         if (CC) {
-            // X0 * conj(X1) / |X0| / |X1|  (runGCCNMF.py:44); 0/0 -> NaN exactly as in the reference
+            // X0 * conj(X1) / |X0| / |X1|  (runGCCNMF.py:44)
             float re = XL.x * XR.x + XL.y * XR.y, im = XL.y * XR.x - XL.x * XR.y;
-            re = re / aL / aR;
-            im = im / aL / aR;
+            if (aL > 0.f && aR > 0.f) {
+                re = re / aL / aR;
+                im = im / aL / aR;
+            } else {
+                re = 0.f;   // a bin that is exactly 0 in f32 carries no phase: it contributes nothing (NaN policy)
+                im = 0.f;
+            }
             float* Cb = CC + (long)b * 2 * plane + (long)f * Tp + t;
             Cb[0] = re;
             Cb[plane] = im;

@@ -118,8 +118,13 @@ __global__ __launch_bounds__(256) void gcc_coherence_kernel(const float2* __rest
     const float2 xr = X[(long)b * 2 * plane + plane + (long)f * Tp + t];
     const float aL = hypotf(xl.x, xl.y), aR = hypotf(xr.x, xr.y);
     float re = xl.x * xr.x + xl.y * xr.y, im = xl.y * xr.x - xl.x * xr.y;
-    re = re / aL / aR;
-    im = im / aL / aR;
+    if (aL > 0.f && aR > 0.f) {
+        re = re / aL / aR;
+        im = im / aL / aR;
+    } else {
+        re = 0.f;   // a bin that is exactly 0 in f32 carries no phase: it contributes nothing (NaN policy)
+        im = 0.f;
+    }
     float* Cb = CC + (long)b * 2 * plane + (long)f * Tp + t;
     Cb[0] = re;
     Cb[plane] = im;

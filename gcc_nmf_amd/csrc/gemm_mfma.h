@@ -101,6 +101,106 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int file, int r
     }
 }
 
+// Epilogue of one wave's pair of 32x32 MFMA tiles (columns col and col+32, same 16 rows per lane:
+// row(r) = row_base + (r&3) + 8*(r>>2)).  Every global LOAD the epilogue needs is issued up front from
+// clamped (always in-bounds) addresses, then the arithmetic, then the predicated stores: a per-element
+// load -> use -> store chain would serialise 128 memory round trips per lane (the in-place H update cannot
+// be reordered by the compiler) and cost as much as the whole k-loop.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, const f32x16& acc_a,
+                                                   const f32x16& acc_b) {
+    const int col_b = col_a + 32;
+    const bool ok_a = gemm_col_valid<EPI>(p, col_a), ok_b = gemm_col_valid<EPI>(p, col_b);
+    if (EPI == EPI_STORE) {
+        float* __restrict__ C = p.C + file * p.sC;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            if (row < p.M) {
+                if (ok_a) C[(long)row * p.ldc + col_a] = acc_a[r];
+                if (ok_b) C[(long)row * p.ldc + col_b] = acc_b[r];
+            }
+        }
+    } else if (EPI == EPI_DIV) {
+        const float* __restrict__ V = p.E0 + file * p.sE0;
+        float* __restrict__ C = p.C + file * p.sC;
+        const int ca = min(col_a, p.N - 1), cb = min(col_b, p.N - 1);
+        float va[16], vb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long ro = (long)min(row_base + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+            va[r] = V[ro + ca];
+            vb[r] = V[ro + cb];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            if (row < p.M) {
+                if (ok_a) C[(long)row * p.ldc + col_a] = va[r] / acc_a[r];
+                if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] / acc_b[r];
+            }
+        }
+    } else if (EPI == EPI_UPDH) {
+        float* C = p.C + file * p.sC;                      // read-modify-write: all reads first
+        const float* __restrict__ E1 = p.E1 ? p.E1 + file * p.sE1 : nullptr;
+        const float* __restrict__ E2 = p.E2 + file * p.sE2;
+        const int ca = min(col_a, p.N - 1), cb = min(col_b, p.N - 1);
+        float ha[16], hb[16], den[16], sc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rc = min(row_base + (r & 3) + 8 * (r >> 2), p.M - 1);
+            ha[r] = C[(long)rc * p.ldc + ca];
+            hb[r] = C[(long)rc * p.ldc + cb];
+            den[r] = E2[rc];
+            sc[r] = E1 ? E1[rc] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const float d = den[r] + p.alpha + p.eps;
+            if (row < p.M) {
+                if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] / d);
+                if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] / d);
+            }
+        }
+    } else {  // EPI_PHASE: one tile at a time (X is two registers per element)
+        const float2* __restrict__ X = p.X + file * p.sX;
+        const float* __restrict__ V = p.E0 + file * p.sE0;
+        float2* __restrict__ C = (float2*)p.C + file * p.sC;
+        const int nic = p.N / p.Tp;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int col = half ? col_b : col_a;
+            const bool ok = half ? ok_b : ok_a;
+            const int ic = min(col / p.Tp, nic - 1);
+            const int t = min(col - (col / p.Tp) * p.Tp, p.T - 1);
+            const int c = ic & 1;
+            float2 x[16];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rc = min(row_base + (r & 3) + 8 * (r >> 2), p.M - 1);
+                x[r] = X[((long)c * p.Fp + rc) * p.Tp + t];
+                v[r] = V[(long)rc * p.ldv + c * p.T + t];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                const float a = half ? acc_b[r] : acc_a[r];
+                float2 o;
+                if (v[r] > 0.f) {
+                    o.x = a * (x[r].x / v[r]);
+                    o.y = a * (x[r].y / v[r]);
+                } else {           // numpy.angle(0) == 0 -> exp(0j) == 1
+                    o.x = a;
+                    o.y = 0.f;
+                }
+                if (ok && row < p.M) C[((long)ic * p.Fp + row) * p.Tp + t] = o;
+            }
+        }
+    }
+}
+
 template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p) {
     constexpr int BK = 16;
@@ -302,16 +402,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     if (wave_active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int col = col0 + wn * 64 + n * 32 + l31;
-                const bool cv = gemm_col_valid<EPI>(p, col);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wm * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (cv && row < p.M) gemm_epilogue<EPI>(p, file, row, col, acc[m][n][r]);
-                }
-            }
+            gemm_epilogue_pair<EPI>(p, file, row0 + wm * 128 + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
     }
     if (TAIL) {
         if (do_tail) {   // block-uniform

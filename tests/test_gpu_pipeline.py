@@ -86,7 +86,14 @@ def test_synthetic_against_oracle_stagewise():
         y = e.separate(x)[0]
         assert np.abs(e.get_X()[0] - r['X']).max() < 1e-5 * np.abs(r['X']).max()
         assert np.abs(e.get_V()[0] - r['V']).max() < 1e-5 * r['V'].max()
-        assert np.abs(e.get_C()[0] - r['C']).max() < 2e-3            # unit-modulus ratio of f32 spectra
+        # the coherence is a unit-modulus RATIO: where |X| sits at the f32 FFT noise floor (~1e-6 max|X|) its phase is
+        # noise in both implementations, so check the kernel's arithmetic on the device's own X, and the oracle's C
+        # only where both channels are well above that floor
+        Xd = e.get_X()[0]
+        C_from_Xd = Xd[0] * Xd[1].conj() / np.abs(Xd[0]) / np.abs(Xd[1])
+        assert np.abs(e.get_C()[0] - C_from_Xd).max() < 1e-5
+        strong = np.minimum(np.abs(r['X'][0]), np.abs(r['X'][1])) > 1e-2 * np.abs(r['X']).max()
+        assert np.abs(e.get_C()[0] - r['C'])[strong].max() < 2e-3
         W, H = e.get_WH()
         assert rel(W[0], r['W']) < 1e-4 and rel(H[0], r['H']) < 1e-4
         ang, meanA = e.get_angular()
@@ -110,6 +117,23 @@ def test_too_few_peaks_is_an_error():
         e.upload(np.full((2, n), np.nan, np.float32))
     with pytest.raises(ValueError):
         e.upload(np.zeros((2, n + 1), np.float32))
+
+
+def test_zero_magnitude_bins_do_not_poison_the_batch():
+    """|X| == 0 bins (a silent channel here; an exactly-cancelling Nyquist bin in practice) give the reference a 0/0 = NaN
+    coherence.  The device path defines their coherence as 0: the silent file fails cleanly with 'too few peaks', its
+    neighbour in the batch is untouched and nothing is NaN."""
+    n = 20000
+    good = O.synthetic_mixture(4, numSamples=n)
+    bad = good.copy()
+    bad[1] = 0
+    e = engine(n, dictionarySize=32, numIterations=5, batch=2)
+    with pytest.raises(ValueError, match=r'file\(s\) \[1\]'):
+        e.separate(np.stack([good, bad]))
+    assert np.isfinite(e.get_angular()[0]).all() and np.isfinite(e.get_C()).all()
+    y0 = e.y[0].cpu().numpy()
+    e1 = engine(n, dictionarySize=32, numIterations=5, batch=1)
+    assert np.array_equal(e1.separate(good)[0], y0)
 
 
 def test_benchmark_shape_properties():
