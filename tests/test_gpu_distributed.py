@@ -1,0 +1,79 @@
+"""-m gpu: the shared-dictionary shard on the device (HipSharedNMF) against the oracle, including the
+two-shards-one-exchange structure of the multi-GPU mode emulated on a single device, and a 1-rank RCCL
+process group driving the real all-reduce call."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import gccnmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def _problem(F, K, cols, seed=1):
+    rng = np.random.RandomState(seed)
+    return [(np.abs(rng.standard_normal((F, n))) + 0.05).astype(np.float32) for n in cols]
+
+
+@pytest.mark.parametrize('F,K,N,B,alpha', [(513, 128, 100, 4, 0), (257, 64, 70, 3, 0.2), (513, 1024, 130, 9, 0)])
+def test_shared_dictionary_matches_performKLNMF_on_concatenation(F, K, N, B, alpha):
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    V = _problem(F, K, [N] * B)
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    local = train_shared_dictionary(HipSharedNMF(V, W0, H0, sparsityAlpha=alpha), 8)
+    Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 8, alpha)
+    W, H = local.W(), np.concatenate(local.H(), axis=1)
+    assert np.linalg.norm(W - Wr) < 1e-4 * np.linalg.norm(Wr)
+    assert np.linalg.norm(H - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
+def test_two_shards_one_exchange():
+    """Ranks' shards as two objects on one device; the all-reduce is the explicit sum of their partial buffers."""
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, shard_files
+    F, K, N, B = 513, 96, 64, 6
+    V = _problem(F, K, [N] * B, seed=3)
+    shards = []
+    for rank in range(2):
+        mine = shard_files(B, 2, rank)
+        W0, H0 = shared_initial_factors(F, [N] * B, K, mine, mode='concat')
+        shards.append(HipSharedNMF([V[i] for i in mine], W0, H0))
+    for s in shards:
+        s.begin()
+    for _ in range(6):
+        parts = [s.step_a() for s in shards]
+        total = parts[0] + parts[1]                  # == dist.all_reduce(SUM) over two ranks
+        for s in shards:
+            s.step_b(total.clone())
+    for s in shards:
+        s.finish()
+    assert np.array_equal(shards[0].W(), shards[1].W())
+    Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 6, 0)
+    H = np.concatenate(shards[0].H() + shards[1].H(), axis=1)
+    assert np.linalg.norm(shards[0].W() - Wr) < 1e-4 * np.linalg.norm(Wr)
+    assert np.linalg.norm(H - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
+def test_rccl_single_rank_group():
+    import torch.distributed as dist
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        t = torch.ones(1024, device='cuda')
+        dist.all_reduce(t)                                     # RCCL call path is alive
+        assert float(t.sum()) == 1024.0
+        F, K, N, B = 129, 32, 40, 2
+        V = _problem(F, K, [N] * B, seed=5)
+        W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+        local = train_shared_dictionary(HipSharedNMF(V, W0, H0), 5)
+        Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 5, 0)
+        assert np.linalg.norm(local.W() - Wr) < 1e-4 * np.linalg.norm(Wr)
+    finally:
+        dist.destroy_process_group()
