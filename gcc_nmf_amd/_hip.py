@@ -19,6 +19,7 @@ STATUS = {0: 'GCCNMF_OK', 1: 'GCCNMF_ERR_ARG (bad argument)', 2: 'GCCNMF_ERR_LAU
 # name -> (restype, argtypes); mirrors include/gccnmf_hip.h declaration by declaration
 SIGNATURES = {
     'gccnmf_version': (c_int, []),
+    'gccnmf_set_tuning': (c_int, [c_int, c_int]),
     'gccnmf_pitches': (c_int, [c_int, c_int, c_int, P_INT, P_INT, P_INT, P_INT]),
     'gccnmf_stft_stereo': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),

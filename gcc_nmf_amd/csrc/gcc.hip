@@ -208,6 +208,11 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
     a.A = W; a.sA = (long)p.Fp * p.Kp; a.lda = p.Kp; a.a_clamp = p.Kp - 4;
     a.B = P; a.sB = (long)p.Fp * ncol; a.ldb = ncol; a.b_clamp = ncol - 4;
     a.M = K; a.N = ncol; a.Kd = F;
+    if ((F % 16) == 1) {
+        a.Kd = F - 1;
+        a.ktailA = W + (long)(F - 1) * p.Kp; a.s_ktailA = a.sA;
+        a.ktailB = P + (long)(F - 1) * ncol; a.s_ktailB = a.sB;
+    }
     a.batch = batch; a.xcd_affine = 1;
     a.C = scores; a.sC = (long)p.Kp * ncol; a.ldc = ncol;
     int rc = (K > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)

@@ -23,6 +23,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// run-time tuning knobs (gccnmf_set_tuning); defined in nmf.hip
+extern int gccnmf_tune_stagger;
+
 enum GemmEpilogue {
     EPI_STORE = 0,   // C[row][col] = acc
     EPI_DIV = 1,     // C[row][col] = E0[row][col] / acc                      (R = V / (W.H),  :76/:77)
@@ -38,9 +41,13 @@ struct GemmArgs {
     int M, N, Kd;              // MFMA output rows, output columns, reduction length
     int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
     int tiles_m, tiles_n, batch, xcd_affine;
+    int stagger;               // experiment: late start (x 8128 cycles) for the workgroup that is second on its CU
     const float* bscale;       // optional per-reduction-index scale applied to B while staging (non-KC B only)
     long s_bscale;
     int tail_row;              // TAIL: index of the extra VALU-computed output row
+    const float* ktailA;       // optional rank-1 reduction tail: acc[row][col] += ktailA[row] * ktailB[col] (the one
+    const float* ktailB;       //   reduction index beyond a multiple of 16, e.g. f = 512 of F = 513, kept off the matrix cores)
+    long s_ktailA, s_ktailB;
     float* rowsumB;            // optional: rowsumB[j] = sum_kk B(kk, j) (KC B only), written by the tm == 0 blocks
     long s_rowsumB;
     float* C;
@@ -107,10 +114,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int file, int r
 // load -> use -> store chain would serialise 128 memory round trips per lane (the in-place H update cannot
 // be reordered by the compiler) and cost as much as the whole k-loop.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, const f32x16& acc_a,
-                                                   const f32x16& acc_b) {
+__device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, f32x16& acc_a,
+                                                   f32x16& acc_b) {
     const int col_b = col_a + 32;
     const bool ok_a = gemm_col_valid<EPI>(p, col_a), ok_b = gemm_col_valid<EPI>(p, col_b);
+    if (EPI == EPI_STORE || EPI == EPI_UPDH) {
+        if (p.ktailA) {   // last reduction index as one fmaf per element, in chain order (it is the final k)
+            const float* __restrict__ ta = p.ktailA + file * p.s_ktailA;
+            const float* __restrict__ tb = p.ktailB + file * p.s_ktailB;
+            const float ba = tb[min(col_a, p.N - 1)], bb = tb[min(col_b, p.N - 1)];
+            float av[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = ta[min(row_base + (r & 3) + 8 * (r >> 2), p.M - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc_a[r] = fmaf(av[r], ba, acc_a[r]);
+                acc_b[r] = fmaf(av[r], bb, acc_b[r]);
+            }
+        }
+    }
     if (EPI == EPI_STORE) {
         float* __restrict__ C = p.C + file * p.sC;
 #pragma unroll
@@ -201,6 +223,69 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
     }
 }
 
+// ---- operand staging: global -> registers (float4 per lane) -> LDS ---------------------------------
+// Free functions on array references (no lambdas: a by-reference lambda capture of the register arrays
+// sent them to scratch memory in the non-KC instantiations -- 144 B/lane of private-memory traffic per tile).
+// Per-thread element offsets of its float4 units inside the operand (loop invariant, 32-bit: one VGPR each);
+// the k-tile origin is folded into the wave-uniform base pointer so the loads use the SGPR-base addressing form.
+template <int BMN, int NT, int U, bool KC>
+__device__ __forceinline__ void gemm_operand_offsets(int (&off)[U], int ld, int origin, int clamp, int tid) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int u = tid + NT * i;
+        if (KC) {
+            const int row = u >> 2, c4 = u & 3;
+            off[i] = min(origin + row, clamp) * ld + 4 * c4;
+        } else {
+            const int kk = u / (BMN / 4), c4 = u - kk * (BMN / 4);
+            off[i] = kk * ld + min(origin + 4 * c4, clamp);
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void gemm_load_operand(float4 (&r)[U], const float* __restrict__ tile_base, const int (&off)[U]) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) r[i] = *(const float4*)(tile_base + off[i]);
+}
+
+template <int BMN, int NT, int U, bool KC, int LD>
+__device__ __forceinline__ void gemm_store_operand(const float4 (&r)[U], float* __restrict__ s, int tid) {
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int u = tid + NT * i;
+        if (KC) {
+            const int row = u >> 2, c4 = u & 3;
+            float* d = s + row * LD + 4 * c4;
+            d[0] = r[i].x;
+            d[1] = r[i].y;
+            d[2] = r[i].z;
+            d[3] = r[i].w;
+        } else {
+            const int kk = u / (BMN / 4), c4 = u - kk * (BMN / 4);
+            // rebuilt from components: copying the array element as a whole demotes the register array to scratch
+            *(float4*)(s + kk * BMN + 4 * c4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+        }
+    }
+}
+
+// MFMA operand fragments of one k-pair: lane (l31, hh) supplies A[i = l31][k = hh] and B[k = hh][j = l31].
+template <int BM, int BN, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void gemm_read_frags(float (&a)[4], float (&b)[2], const float* __restrict__ sA,
+                                                const float* __restrict__ sB, int arow, int bcol, int kk) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = A_KC ? sA[(arow + m * 32) * LDA + kk] : sA[kk * BM + arow + m * 32];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b[n] = B_KC ? sB[(bcol + n * 32) * LDB + kk] : sB[kk * BN + bcol + n * 32];
+}
+
+__device__ __forceinline__ void gemm_mma8(f32x16 (&acc)[4][2], const float (&a)[4], const float (&b)[2]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+}
+
 template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p) {
     constexpr int BK = 16;
@@ -210,16 +295,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     constexpr int LDB = B_KC ? (BK + 1) : BN;
     constexpr int SA = A_KC ? BM * LDA : BK * BM;
     constexpr int SB = B_KC ? BN * LDB : BK * BN;
-    constexpr int UA = BM * 4 / NT;   // float4 units of the A tile per thread
+    constexpr int SBUF = SA + SB + BK;      // one staging buffer: A tile | B tile | tail row of A
+    constexpr int UA = BM * 4 / NT;         // float4 units of the A tile per thread
     constexpr int UB = BN * 4 / NT;
     static_assert(UA >= 1 && UB >= 1 && UA * NT == BM * 4 && UB * NT == BN * 4, "tile/thread mismatch");
     static_assert(!TAIL || A_KC, "the VALU tail row needs a reduction-contiguous A");
     static_assert(NT % BN == 0 || BN % NT == 0, "tail mapping");
+    static_assert(SBUF % 4 == 0 && SA % 4 == 0 && SB % 4 == 0, "16-byte aligned LDS carve");
 
-    __shared__ __attribute__((aligned(16))) float smem[SA + SB + BK];
-    float* sA = smem;
-    float* sB = smem + SA;
-    float* sT = smem + SA + SB;
+    // two staging buffers: tile t is computed from buffer t&1 while tile t+1 is written into the other one
+    __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
 
     // ---- which (file, tile) is this workgroup? ------------------------------------------
     const int tiles = p.tiles_m * p.tiles_n;
@@ -242,14 +327,23 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, hh = lane >> 5;
+    const int arow = wm * 128 + l31, bcol = wn * 64 + l31;
 
     const float* __restrict__ A = p.A + file * p.sA;
     const float* __restrict__ B = p.B + file * p.sB;
-    const float* __restrict__ bscale = p.bscale ? p.bscale + file * p.s_bscale : nullptr;
+    const float* __restrict__ bscale = (!B_KC && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
 
     const bool wave_active = (row0 + wm * 128) < p.M;
     const bool do_tail = TAIL && (tm == 0);
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr) && (tm == 0);
+
+    if (p.stagger) {
+        // co-resident workgroups start in lockstep and then hit their prologue/epilogue memory bursts together;
+        // the one that does not own LDS offset 0 starts late so that its neighbour's MFMAs cover those phases
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 6);   // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base != 0)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -260,117 +354,84 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
-    float4 ra[UA], rb[UB], rt;
+    int offA[UA], offB[UB];
+    gemm_operand_offsets<BM, NT, UA, A_KC>(offA, p.lda, row0, p.a_clamp, tid);
+    gemm_operand_offsets<BN, NT, UB, B_KC>(offB, p.ldb, col0, p.b_clamp, tid);
+    float4 ra[UA], rb[UB];
+    float4 rt = make_float4(0.f, 0.f, 0.f, 0.f);
     float rsc[UB];
 #pragma unroll
-    for (int r = 0; r < UB; ++r) rsc[r] = 1.f;
-    rt = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < UB; ++i) rsc[i] = 1.f;
 
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int r = 0; r < UA; ++r) {
-            const int u = tid + NT * r;
-            if (A_KC) {
-                const int row = u >> 2, c4 = u & 3;
-                const int grow = min(row0 + row, p.a_clamp);
-                ra[r] = *(const float4*)(A + (long)grow * p.lda + k0 + 4 * c4);
-            } else {
-                const int kk = u / (BM / 4), c4 = u - kk * (BM / 4);
-                const int gcol = min(row0 + 4 * c4, p.a_clamp);
-                ra[r] = *(const float4*)(A + (long)(k0 + kk) * p.lda + gcol);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < UB; ++r) {
-            const int u = tid + NT * r;
-            if (B_KC) {
-                const int row = u >> 2, c4 = u & 3;
-                const int grow = min(col0 + row, p.b_clamp);
-                rb[r] = *(const float4*)(B + (long)grow * p.ldb + k0 + 4 * c4);
-            } else {
-                const int kk = u / (BN / 4), c4 = u - kk * (BN / 4);
-                const int gcol = min(col0 + 4 * c4, p.b_clamp);
-                rb[r] = *(const float4*)(B + (long)(k0 + kk) * p.ldb + gcol);
-                if (bscale) rsc[r] = bscale[k0 + kk];   // consumed in store_tiles: no wait on it here
-            }
-        }
-        if (TAIL) {
-            if (do_tail && tid < 4) rt = *(const float4*)(A + (long)p.tail_row * p.lda + k0 + 4 * tid);
-        }
-    };
+#define GEMM_LOAD_TILE(k0_)                                                                                     \
+    do {                                                                                                        \
+        gemm_load_operand<UA>(ra, A + (A_KC ? (long)(k0_) : (long)(k0_) * p.lda), offA);                        \
+        gemm_load_operand<UB>(rb, B + (B_KC ? (long)(k0_) : (long)(k0_) * p.ldb), offB);                        \
+        if (!B_KC) {                                                                                            \
+            if (bscale) {                                                                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < UB; ++i_) rsc[i_] = bscale[(k0_) + (tid + NT * i_) / (BN / 4)]; \
+            }                                                                                                   \
+        }                                                                                                       \
+        if (TAIL) {                                                                                             \
+            if (do_tail && tid < 4) rt = *(const float4*)(A + (long)p.tail_row * p.lda + (k0_) + 4 * tid);      \
+        }                                                                                                       \
+    } while (0)
 
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int r = 0; r < UA; ++r) {
-            const int u = tid + NT * r;
-            if (A_KC) {
-                const int row = u >> 2, c4 = u & 3;
-                float* d = sA + row * LDA + 4 * c4;
-                d[0] = ra[r].x;
-                d[1] = ra[r].y;
-                d[2] = ra[r].z;
-                d[3] = ra[r].w;
-            } else {
-                const int kk = u / (BM / 4), c4 = u - kk * (BM / 4);
-                *(float4*)(sA + kk * BM + 4 * c4) = ra[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < UB; ++r) {
-            const int u = tid + NT * r;
-            if (B_KC) {
-                const int row = u >> 2, c4 = u & 3;
-                float* d = sB + row * LDB + 4 * c4;
-                d[0] = rb[r].x;
-                d[1] = rb[r].y;
-                d[2] = rb[r].z;
-                d[3] = rb[r].w;
-            } else {
-                const int kk = u / (BN / 4), c4 = u - kk * (BN / 4);
-                float4 v = rb[r];
-                if (bscale) {
-                    v.x *= rsc[r];
-                    v.y *= rsc[r];
-                    v.z *= rsc[r];
-                    v.w *= rsc[r];
-                }
-                *(float4*)(sB + kk * BN + 4 * c4) = v;
-            }
-        }
-        if (TAIL) {
-            if (do_tail && tid < 4) *(float4*)(sT + 4 * tid) = rt;
-        }
-    };
+#define GEMM_STORE_TILE(buf_)                                                                                   \
+    do {                                                                                                        \
+        float* sbuf_ = smem + (buf_) * SBUF;                                                                    \
+        gemm_store_operand<BM, NT, UA, A_KC, LDA>(ra, sbuf_, tid);                                              \
+        if (!B_KC) {                                                                                            \
+            if (bscale) {   /* the lazy H row scale rides on the staging pass (the wait on it happens here) */  \
+                _Pragma("unroll") for (int i_ = 0; i_ < UB; ++i_) {                                             \
+                    rb[i_].x *= rsc[i_];                                                                        \
+                    rb[i_].y *= rsc[i_];                                                                        \
+                    rb[i_].z *= rsc[i_];                                                                        \
+                    rb[i_].w *= rsc[i_];                                                                        \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+        gemm_store_operand<BN, NT, UB, B_KC, LDB>(rb, sbuf_ + SA, tid);                                         \
+        if (TAIL) {                                                                                             \
+            if (do_tail && tid < 4) *(float4*)(sbuf_ + SA + SB + 4 * tid) = rt;                                 \
+        }                                                                                                       \
+    } while (0)
 
     const int nkt = (p.Kd + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles();
+    GEMM_LOAD_TILE(0);
+    GEMM_STORE_TILE(0);
+    if (nkt > 1) GEMM_LOAD_TILE(BK);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tiles((kt + 1) * BK);   // in flight under this tile's MFMAs
+        const int cur = kt & 1;
+        // tile kt+1 (in registers since the previous iteration) -> the other buffer; tile kt+2 -> registers.
+        // One barrier per tile: buffer cur^1 was last read in iteration kt-1, which every wave has left.
+        if (kt + 1 < nkt) GEMM_STORE_TILE(cur ^ 1);
+        if (kt + 2 < nkt) GEMM_LOAD_TILE((kt + 2) * BK);
 
+        const float* __restrict__ sA = smem + cur * SBUF;
+        const float* __restrict__ sB = sA + SA;
+        const float* __restrict__ sT = sB + SB;
         if (wave_active) {
+            // software-pipelined fragments: the reads of k-pair p+1 are in flight under the 8 MFMAs of k-pair p
+            float a0[4], b0[2], a1[4], b1[2];
+            gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a0, b0, sA, sB, arow, bcol, hh);
 #pragma unroll
-            for (int pp = 0; pp < BK / 2; ++pp) {
-                const int kk = 2 * pp + hh;
-                float a[4], b[2];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    a[m] = A_KC ? sA[(wm * 128 + m * 32 + l31) * LDA + kk] : sA[kk * BM + wm * 128 + m * 32 + l31];
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    b[n] = B_KC ? sB[(wn * 64 + n * 32 + l31) * LDB + kk] : sB[kk * BN + wn * 64 + n * 32 + l31];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            for (int pp = 0; pp < BK / 2; pp += 2) {
+                gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a1, b1, sA, sB, arow, bcol, 2 * (pp + 1) + hh);
+                __builtin_amdgcn_sched_barrier(0);
+                gemm_mma8(acc, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp + 2 < BK / 2) gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a0, b0, sA, sB, arow, bcol, 2 * (pp + 2) + hh);
+                __builtin_amdgcn_sched_barrier(0);
+                gemm_mma8(acc, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (TAIL) {
             if (do_tail) {
-                // NT >= BN: NT/BN thread groups split the 16 reduction steps; NT < BN never happens with TAIL configs
+                // NT/BN thread groups split the 16 reduction steps of the extra output row
                 constexpr int G = (NT >= BN) ? NT / BN : 1;
                 constexpr int PER = BK / G;
                 const int j = tid % BN, g = tid / BN;
@@ -394,9 +455,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
             }
         }
         __syncthreads();
-        if (kt + 1 < nkt) store_tiles();
-        __syncthreads();
     }
+#undef GEMM_LOAD_TILE
+#undef GEMM_STORE_TILE
 
     // ---- epilogue: MFMA C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------
     if (wave_active) {
@@ -407,12 +468,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     if (TAIL) {
         if (do_tail) {   // block-uniform
             constexpr int G = (NT >= BN) ? NT / BN : 1;
-            sA[tid] = tail_acc;     // sA is free after the final barrier of the k loop
+            smem[tid] = tail_acc;     // the staging buffers are free after the final barrier of the k loop
             __syncthreads();
             if (tid < BN) {
                 float s = 0.f;
 #pragma unroll
-                for (int g = 0; g < G; ++g) s += sA[g * BN + tid];
+                for (int g = 0; g < G; ++g) s += smem[g * BN + tid];
                 const int col = col0 + tid;
                 if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, file, p.tail_row, col, s);
             }
@@ -435,6 +496,7 @@ static int gccnmf_launch_gemm(GemmArgs a, hipStream_t stream) {
     constexpr int BM = WM * 128, BN = WN * 64, NT = WM * WN * 64;
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
     if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;   // float4 staging
+    a.stagger = gccnmf_tune_stagger;
     a.tiles_m = gccnmf_ceil_div(a.M, BM);
     a.tiles_n = gccnmf_ceil_div(a.N, BN);
     const int tiles = a.tiles_m * a.tiles_n;

@@ -12,8 +12,18 @@
 // gccnmf_klnmf materialises it once after the last iteration.
 #include "gemm_mfma.h"
 
+int gccnmf_tune_stagger = 0;
+
 extern "C" {
-int gccnmf_version(void) { return 100; }
+int gccnmf_version(void) { return 101; }
+
+int gccnmf_set_tuning(int key, int value) {
+    if (key == 0) {
+        gccnmf_tune_stagger = value;
+        return GCCNMF_OK;
+    }
+    return GCCNMF_ERR_ARG;
+}
 
 int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
     if (F < 2 || T < 1 || K < 1 || !Fp || !Kp || !Np || !Tp) return GCCNMF_ERR_ARG;
@@ -180,6 +190,11 @@ static int launch_update_h(const NmfGeom& g, const float* W, long sW, const floa
     a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Kp - 4;
     a.B = R; a.sB = g.sV; a.ldb = g.Np; a.b_clamp = g.Np - 4;
     a.M = g.K; a.N = g.N; a.Kd = g.F;
+    if ((g.F % 16) == 1) {   // F = 16*n + 1: bin F-1 leaves the matrix cores and becomes a rank-1 term of the epilogue
+        a.Kd = g.F - 1;
+        a.ktailA = W + (long)(g.F - 1) * g.Kp; a.s_ktailA = sW;
+        a.ktailB = R + (long)(g.F - 1) * g.Np; a.s_ktailB = g.sV;
+    }
     a.batch = batch; a.xcd_affine = xcd;
     a.C = H; a.sC = g.sH; a.ldc = g.Np;
     a.E1 = hscale; a.sE1 = sScale;
@@ -355,6 +370,12 @@ int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, in
     a.B = B; a.sB = sB; a.ldb = ldb; a.b_clamp = b_clamp;
     const bool tail = layout & 4;
     a.M = tail ? M - 1 : M; a.N = N; a.Kd = Kd;
+    if (layout & 16) {   // rank-1 reduction tail (non-KC operands only)
+        if (layout & 3) return GCCNMF_ERR_ARG;
+        a.Kd = Kd - 1;
+        a.ktailA = A + (long)(Kd - 1) * lda; a.s_ktailA = sA;
+        a.ktailB = B + (long)(Kd - 1) * ldb; a.s_ktailB = sB;
+    }
     a.tail_row = M - 1;
     a.batch = batch; a.xcd_affine = 1;
     a.bscale = bscale; a.s_bscale = 0;

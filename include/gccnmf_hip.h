@@ -39,6 +39,10 @@ extern "C" {
 
 int gccnmf_version(void);
 
+/* Experiment knobs (process-global).  key 0: start-up stagger of the second co-resident GEMM workgroup, in units of
+ * 8128 shader cycles (0 = off). */
+int gccnmf_set_tuning(int key, int value);
+
 /* Padded geometry every other entry point assumes. */
 int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
 
@@ -140,7 +144,8 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
 
 /* Diagnostics (tests only): run one MFMA GEMM configuration in isolation.
- * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid. */
+ * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid,
+ * 16 = last reduction index as a rank-1 epilogue term (non-KC operands). */
 int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc,
                       int a_clamp, int b_clamp, int layout, int batch, long sA, long sB, long sC,
                       const float* bscale, float* rowsumB, void* stream);

@@ -22,11 +22,13 @@ def main():
     ap.add_argument('--T', type=int, default=622)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--flags', type=int, default=0)
+    ap.add_argument('--stagger', type=int, default=0)
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
+    lib.gccnmf_set_tuning(0, a.stagger)
     F, T, K, B = 513, a.T, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N

@@ -51,6 +51,7 @@ GEMM_CASES = [
     (1 | 4 | 8, 129, 260, 40, 1),
     (3, 200, 64, 150, 1), (3 | 4, 513, 128, 300, 2), (3 | 4, 513, 200, 1244, 8), (3 | 8, 100, 256, 75, 1),
     (3 | 4 | 8, 129, 300, 50, 2),
+    (16, 1024, 200, 513, 2), (16 | 8, 128, 300, 33, 9), (16, 300, 100, 17, 1),      # rank-1 reduction tail in the epilogue
 ]
 
 
@@ -88,7 +89,7 @@ def test_debug_gemm(hip, layout, M, N, Kd, batch):
     dC = torch.full((batch, M, ldc), -7.0, dtype=torch.float32, device='cuda')
     bscale = None
     dscale = None
-    if not b_kc:
+    if not b_kc and not (layout & 16):
         bscale = (rng.rand(Kd16) + 0.5).astype(np.float32)
         dscale = dev(bscale)
     drow = torch.zeros((batch, N), dtype=torch.float32, device='cuda') if b_kc else None
