@@ -24,13 +24,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // run-time tuning knobs (gccnmf_set_tuning); defined in nmf.hip
-extern int gccnmf_tune_stagger;
+extern int gccnmf_tune_ablate;
 
 enum GemmEpilogue {
     EPI_STORE = 0,   // C[row][col] = acc
     EPI_DIV = 1,     // C[row][col] = E0[row][col] / acc                      (R = V / (W.H),  :76/:77)
     EPI_UPDH = 2,    // C[row][col] = (C[row][col]*E1[row]) * (acc / (E2[row] + alpha + eps))   (H update, :76)
-    EPI_PHASE = 3    // Cx[ic][row][t] = acc * X[c][row][t] / |X|              (:150-151)
+    EPI_PHASE = 3,   // Cx[ic][row][t] = acc * X[c][row][t] / |X|              (:150-151)
+    EPI_UPDW = 4     // block-level: W = normalise(W * acc / rowsum(B)); the tile must own every row  (:77,:79-80)
 };
 
 struct GemmArgs {
@@ -41,13 +42,16 @@ struct GemmArgs {
     int M, N, Kd;              // MFMA output rows, output columns, reduction length
     int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
     int tiles_m, tiles_n, batch, xcd_affine;
-    int stagger;               // experiment: late start (x 8128 cycles) for the workgroup that is second on its CU
+    int ablate;                // timing experiments: 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row, 16 no epilogue (results invalid)
     const float* bscale;       // optional per-reduction-index scale applied to B while staging (non-KC B only)
     long s_bscale;
     int tail_row;              // TAIL: index of the extra VALU-computed output row
     const float* ktailA;       // optional rank-1 reduction tail: acc[row][col] += ktailA[row] * ktailB[col] (the one
     const float* ktailB;       //   reduction index beyond a multiple of 16, e.g. f = 512 of F = 513, kept off the matrix cores)
     long s_ktailA, s_ktailB;
+    float* out_colsum;         // EPI_UPDW outputs: column sums of the new W, and the atom norms (the lazy H row scale)
+    float* out_norm;
+    long s_out;
     float* rowsumB;            // optional: rowsumB[j] = sum_kk B(kk, j) (KC B only), written by the tm == 0 blocks
     long s_rowsumB;
     float* C;
@@ -286,6 +290,112 @@ __device__ __forceinline__ void gemm_mma8(f32x16 (&acc)[4][2], const float (&a)[
         for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
 }
 
+// EPI_UPDW: the W update, unit-L2 atom normalisation and the K-vectors of the next iteration, fused behind U = R.H^T
+// (gccNMFFunctions.py:77,79-80).  The <4,1> workgroup owns all F rows of its 64 atoms (512 on the matrix cores + the
+// VALU tail row), so the column norms are a workgroup-local reduction: lanes -> row halves (shuffle) -> waves (LDS).
+//   Wt = W * (U / rowsumH);  norm = sqrt(sum_f Wt^2);  W = Wt / norm;  colsum = sum_f W;  hscale = norm
+template <bool TAIL>
+__device__ __forceinline__ void gemm_epilogue_update_w(const GemmArgs& p, int file, int col0, int tid, int wm, int l31, int hh,
+                                                       f32x16 (&acc)[4][2], float tail_acc, float rowsum_acc, float* smem) {
+    float* s_rs = smem;              // [64]     rowsum of H per atom
+    float* s_tail = smem + 64;       // [4][64]  partial dot products of the tail row
+    float* s_red = smem + 320;       // [5][64]  per-wave (+ tail row) partial column reductions
+    float* s_norm = smem + 640;      // [64]
+    float rs = rowsum_acc;
+    rs += __shfl_xor(rs, 1);
+    rs += __shfl_xor(rs, 2);
+    if ((tid & 3) == 0) s_rs[tid >> 2] = rs;
+    if (TAIL) s_tail[tid] = tail_acc;
+    __syncthreads();
+    const int ca = l31, cb = l31 + 32;
+    const int ka = col0 + ca, kb = col0 + cb;
+    const bool oka = ka < p.N, okb = kb < p.N;
+    const int kac = min(ka, p.N - 1), kbc = min(kb, p.N - 1);
+    const float rsa = s_rs[ca], rsb = s_rs[cb];
+    float* W = p.C + file * p.sC;
+    float ssa = 0.f, ssb = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int rbase = wm * 128 + m * 32 + 4 * hh;
+        float wa[16], wb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long ro = (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+            wa[r] = W[ro + kac];
+            wb[r] = W[ro + kbc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = (rbase + (r & 3) + 8 * (r >> 2)) < p.M;
+            const float ta = (valid && oka) ? wa[r] * (acc[m][0][r] / rsa) : 0.f;
+            const float tb = (valid && okb) ? wb[r] * (acc[m][1][r] / rsb) : 0.f;
+            acc[m][0][r] = ta;
+            acc[m][1][r] = tb;
+            ssa = fmaf(ta, ta, ssa);
+            ssb = fmaf(tb, tb, ssb);
+        }
+    }
+    ssa += __shfl_xor(ssa, 32);
+    ssb += __shfl_xor(ssb, 32);
+    if (hh == 0) {
+        s_red[wm * 64 + ca] = ssa;
+        s_red[wm * 64 + cb] = ssb;
+    }
+    float wt_tail = 0.f;
+    const bool tail_ok = TAIL && tid < 64 && (col0 + tid) < p.N;
+    if (tid < 64) {
+        if (tail_ok) {
+            const float u = (s_tail[tid] + s_tail[64 + tid]) + (s_tail[128 + tid] + s_tail[192 + tid]);
+            wt_tail = W[(long)p.tail_row * p.ldc + col0 + tid] * (u / s_rs[tid]);
+        }
+        s_red[256 + tid] = wt_tail * wt_tail;
+    }
+    __syncthreads();
+    if (tid < 64) s_norm[tid] = sqrtf(((s_red[tid] + s_red[64 + tid]) + (s_red[128 + tid] + s_red[192 + tid])) + s_red[256 + tid]);
+    __syncthreads();
+    const float na = s_norm[ca], nb = s_norm[cb];
+    float csa = 0.f, csb = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int rbase = wm * 128 + m * 32 + 4 * hh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row < p.M) {
+                if (oka) {
+                    const float wn = acc[m][0][r] / na;
+                    W[(long)row * p.ldc + ka] = wn;
+                    csa += wn;
+                }
+                if (okb) {
+                    const float wn = acc[m][1][r] / nb;
+                    W[(long)row * p.ldc + kb] = wn;
+                    csb += wn;
+                }
+            }
+        }
+    }
+    csa += __shfl_xor(csa, 32);
+    csb += __shfl_xor(csb, 32);
+    if (hh == 0) {
+        s_red[wm * 64 + ca] = csa;
+        s_red[wm * 64 + cb] = csb;
+    }
+    if (tid < 64) {
+        float wn_tail = 0.f;
+        if (tail_ok) {
+            wn_tail = wt_tail / s_norm[tid];
+            W[(long)p.tail_row * p.ldc + col0 + tid] = wn_tail;
+        }
+        s_red[256 + tid] = wn_tail;
+    }
+    __syncthreads();
+    if (tid < 64 && (col0 + tid) < p.N) {
+        p.out_colsum[file * p.s_out + col0 + tid] = ((s_red[tid] + s_red[64 + tid]) + (s_red[128 + tid] + s_red[192 + tid])) + s_red[256 + tid];
+        p.out_norm[file * p.s_out + col0 + tid] = s_norm[tid];
+    }
+}
+
 template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p) {
     constexpr int BK = 16;
@@ -334,16 +444,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     const float* __restrict__ bscale = (!B_KC && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
 
     const bool wave_active = (row0 + wm * 128) < p.M;
-    const bool do_tail = TAIL && (tm == 0);
-    const bool do_rowsum = B_KC && (p.rowsumB != nullptr) && (tm == 0);
-
-    if (p.stagger) {
-        // co-resident workgroups start in lockstep and then hit their prologue/epilogue memory bursts together;
-        // the one that does not own LDS offset 0 starts late so that its neighbour's MFMAs cover those phases
-        const unsigned lds_base = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 6);   // HW_REG_LDS_ALLOC.LDS_BASE
-        if (lds_base != 0)
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    const bool do_tail = TAIL && (tm == 0) && !(p.ablate & 8);
+    const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -407,8 +509,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
         const int cur = kt & 1;
         // tile kt+1 (in registers since the previous iteration) -> the other buffer; tile kt+2 -> registers.
         // One barrier per tile: buffer cur^1 was last read in iteration kt-1, which every wave has left.
-        if (kt + 1 < nkt) GEMM_STORE_TILE(cur ^ 1);
-        if (kt + 2 < nkt) GEMM_LOAD_TILE((kt + 2) * BK);
+        if (kt + 1 < nkt && !(p.ablate & 2)) GEMM_STORE_TILE(cur ^ 1);
+        if (kt + 2 < nkt && !(p.ablate & 1)) GEMM_LOAD_TILE((kt + 2) * BK);
 
         const float* __restrict__ sA = smem + cur * SBUF;
         const float* __restrict__ sB = sA + SA;
@@ -454,13 +556,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
                 }
             }
         }
-        __syncthreads();
+        if (!(p.ablate & 4)) __syncthreads();   // ablate: timing experiments only
     }
 #undef GEMM_LOAD_TILE
 #undef GEMM_STORE_TILE
 
     // ---- epilogue: MFMA C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------
-    if (wave_active) {
+    if (EPI == EPI_UPDW) {
+        static_assert(EPI != EPI_UPDW || (WM == 4 && WN == 1 && B_KC), "the fused W update needs the tall tile that owns every row");
+        gemm_epilogue_update_w<TAIL>(p, file, col0, tid, wm, l31, hh, acc, tail_acc, rowsum_acc, smem);
+        return;
+    }
+    if (p.ablate & 16) {   // timing experiment: keep the accumulators alive, store one value per lane
+        float keep = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[m][n][r];
+        if (wave_active && keep == 123.456f) p.C[file * p.sC] = keep;
+    } else if (wave_active) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
             gemm_epilogue_pair<EPI>(p, file, row0 + wm * 128 + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
@@ -496,7 +612,7 @@ static int gccnmf_launch_gemm(GemmArgs a, hipStream_t stream) {
     constexpr int BM = WM * 128, BN = WN * 64, NT = WM * WN * 64;
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
     if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;   // float4 staging
-    a.stagger = gccnmf_tune_stagger;
+    a.ablate = gccnmf_tune_ablate;
     a.tiles_m = gccnmf_ceil_div(a.M, BM);
     a.tiles_n = gccnmf_ceil_div(a.N, BN);
     const int tiles = a.tiles_m * a.tiles_n;

@@ -12,14 +12,14 @@
 // gccnmf_klnmf materialises it once after the last iteration.
 #include "gemm_mfma.h"
 
-int gccnmf_tune_stagger = 0;
+int gccnmf_tune_ablate = 0;
 
 extern "C" {
 int gccnmf_version(void) { return 101; }
 
 int gccnmf_set_tuning(int key, int value) {
-    if (key == 0) {
-        gccnmf_tune_stagger = value;
+    if (key == 1) {
+        gccnmf_tune_ablate = value;
         return GCCNMF_OK;
     }
     return GCCNMF_ERR_ARG;
@@ -34,6 +34,27 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
     *Tp = p.Tp;
     return GCCNMF_OK;
 }
+}
+
+// MFMA-only probe: what the f32 matrix pipe sustains on this box (clock included), nothing but 8 independent
+// accumulator chains per wave, two waves per SIMD.  grid = 512 blocks of 256 threads.
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(float* out, int iters) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -217,6 +238,22 @@ static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U
     return dispatch_gemm<true, true, EPI_STORE>(a, g.tail, s);
 }
 
+// W = normalise(W * (R.H^T) / rowsumH), colsumW, hscale -- K4a and K4b in one launch (tall tile, all F rows in one workgroup)
+static bool can_fuse_w_update(const NmfGeom& g) { return g.Fm > 128 && g.Fm <= 512; }
+
+static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H, float* W, float* colsumW, float* hscale, int batch,
+                               int xcd, hipStream_t s) {
+    GemmArgs a = {};
+    a.A = R; a.sA = g.sV; a.lda = g.Np; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
+    a.M = g.Fm; a.N = g.K; a.Kd = g.N;
+    a.batch = batch; a.xcd_affine = xcd;
+    a.tail_row = g.F - 1;
+    a.C = W; a.sC = g.sW; a.ldc = g.Kp;
+    a.out_colsum = colsumW; a.out_norm = hscale; a.s_out = g.Kp;
+    return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, false>(a, s);
+}
+
 extern "C" {
 
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
@@ -245,8 +282,11 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
         case 1: return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
         case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
         case 3: return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
-        case 4: return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
+        case 4:
+            if (can_fuse_w_update(g) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
+            return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
         case 5:
+            if (can_fuse_w_update(g) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
             hipLaunchKernelGGL(nmf_update_w_kernel, dim3(vec_grid), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, g.F, g.Fp,
                                g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp);
             break;
@@ -358,6 +398,13 @@ int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, 
     hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, w.hscale, 0L, g.K, g.Kp, g.Np);
     GCCNMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.hscale, 1.f, (long)g.Kp);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
+    if (!scratch || blocks < 1 || iters < 1) return GCCNMF_ERR_ARG;
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

@@ -36,11 +36,13 @@ extern "C" {
 
 /* flags for gccnmf_klnmf */
 #define GCCNMF_FLAG_NO_XCD_AFFINITY 1   /* plain file-major block order instead of the XCD-affine map */
+#define GCCNMF_FLAG_UNFUSED_W_UPDATE 2   /* R.H^T and the W update/normalisation as two launches (always so when F-1 > 512) */
 
 int gccnmf_version(void);
 
-/* Experiment knobs (process-global).  key 0: start-up stagger of the second co-resident GEMM workgroup, in units of
- * 8128 shader cycles (0 = off). */
+/* Timing-experiment knob (process-global, results become INVALID while non-zero).  key 1: ablation bits for the GEMM
+ * kernels -- 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row, 16 no epilogue (DESIGN.md 'where the
+ * time goes' quotes these). */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -142,6 +144,10 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
  *   y      [batch][nsig][L] float32 out, L = n_fft + hop*(T-1) - (center ? n_fft : 0) */
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
+
+/* Diagnostics: a pure v_mfma_f32_32x32x2_f32 loop (blocks x 4 waves x iters x 8 instructions, 2*32*32*2 flop each):
+ * the matrix-pipe rate this box sustains, quoted next to the roofline fractions. */
+int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);
 
 /* Diagnostics (tests only): run one MFMA GEMM configuration in isolation.
  * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid,

@@ -22,13 +22,13 @@ def main():
     ap.add_argument('--T', type=int, default=622)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--flags', type=int, default=0)
-    ap.add_argument('--stagger', type=int, default=0)
+    ap.add_argument('--ablate', type=int, default=0)
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
-    lib.gccnmf_set_tuning(0, a.stagger)
+    lib.gccnmf_set_tuning(1, a.ablate)
     F, T, K, B = 513, a.T, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N
@@ -61,7 +61,22 @@ def main():
         'K1 shape, store only (A_KC, tail)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Fp * g.Np),
         'K2 shape, store only (W^T.R)': lambda: dbg(W, R, G2, K, N, F, g.Kp, g.Np, g.Np, g.Kp - 4, g.Np - 4, 0, g.Fp * g.Kp, g.Fp * g.Np, g.Kp * g.Np),
         'K4a shape, store only (KC,KC, tail)': lambda: dbg(R, H, U, F, K, N, g.Np, g.Np, g.Kp, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Kp),
+        'K1 shape -> other output buffer': lambda: dbg(W, H, G2, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
+        'K1 shape, N=1280 (full last tile)': lambda: dbg(W, H, G2, F, g.Np, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
+        'K1 shape, no tail row (M=512)': lambda: dbg(W, H, G2, 512, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
+        'K4a shape -> R buffer': lambda: dbg(V, H, R, F, K, N, g.Np, g.Np, g.Np, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Np),
     }
+    # pure-MFMA probe: 512 blocks x 4 waves x 8 x 4096 MFMAs
+    scratch = torch.zeros(16, device=dev)
+    for blocks in (256, 512, 1024):
+        lib.gccnmf_debug_mfma_peak(_ptr(scratch), blocks, 4096, _stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.gccnmf_debug_mfma_peak(_ptr(scratch), blocks, 4096, _stream())
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        print('mfma-only probe %4d blocks: %.3f ms  %.1f TF/s' % (blocks, ms, blocks * 4 * 8 * 4096 * 4096.0 / (ms * 1e-3) / 1e12))
     stage(0)
     for _ in range(2):
         for s in range(1, 6):

@@ -327,3 +327,30 @@ def test_reference_call_sequence_dropin(hip, scene):
     assert targetSignalEstimates.shape == r['y'].shape and targetSignalEstimates.dtype == np.float32
     rms = np.sqrt(np.mean((targetSignalEstimates.astype(np.float64) - r['y']) ** 2))
     assert rms < 1e-4, rms
+
+
+@pytest.mark.parametrize('F,T,K', [(513, 40, 128), (257, 33, 64), (200, 50, 100)])
+def test_klnmf_fused_and_unfused_w_update_agree(hip, F, T, K):
+    """The W update + normalisation fused into the R.H^T epilogue (default when 128 < F-1 <= 512) against the two-launch
+    form (GCCNMF_FLAG_UNFUSED_W_UPDATE) and the oracle."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
+    N, B = 2 * T, 3
+    g = Geometry(F, T, K)
+    rng = np.random.RandomState(F + K)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    res = []
+    for flags in (0, 2):
+        dV = padded(V, (B, g.Fp, g.Np), 'cuda')
+        dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
+        dH = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
+        ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
+        assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, 6, 0.0, 1e-16, flags, stream()) == 0
+        res.append((dW.cpu().numpy(), dH.cpu().numpy()))
+    (Wf, Hf), (Wu, Hu) = res
+    assert rel(Wf, Wu) < 1e-5 and rel(Hf, Hu) < 1e-5
+    assert not Wf[:, F:, :].any() and not Wf[:, :, K:].any()
+    for b in range(B):
+        Wr, Hr = O.performKLNMF(V[b], K, 6, 0)
+        assert rel(Wf[b, :F, :K], Wr) < 1e-4 and rel(Hf[b, :K, :N], Hr) < 1e-4
