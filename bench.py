@@ -70,8 +70,18 @@ def kernel_timings(e, reps):
             stage(s)
             ev[r][s].record()
     torch.cuda.synchronize()
-    ms = np.array([[ev[r][s - 1].elapsed_time(ev[r][s]) for s in range(1, 6)] for r in range(reps)])
-    return ms.mean(axis=0)
+    ms = np.array([[ev[r][s - 1].elapsed_time(ev[r][s]) for s in range(1, 6)] for r in range(reps)]).mean(axis=0)
+    # The dominant kernel (K3 == K1 without the row scale: R = V/(W.H)) is a pure function of V, W, H, so it can be launched
+    # back to back: one event pair around `n` launches gives its average duration without the event gaps of the loop above.
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stage(3)
+    e0.record()
+    for _ in range(n):
+        stage(3)
+    e1.record()
+    torch.cuda.synchronize()
+    return ms, e0.elapsed_time(e1) / n
 
 
 def main():
@@ -137,8 +147,16 @@ def main():
         'tdoa_indexes_as_expected': idx_ok,
     }
 
+    if rank == 0:
+        # host float32 samples in -> host float32 waveforms out (PCIe both ways); reported beside `value`, never as `value`
+        t1 = time.perf_counter()
+        e.separate(xs)
+        out['host_to_host_frames_per_s'] = B * g.T / (time.perf_counter() - t1)
+        traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
+
     if rank == 0 and not a.skip_roofline:
-        ms = kernel_timings(e, reps=5)
+        ms, k3_ms = kernel_timings(e, reps=5)
         flop_per_launch = 2.0 * g.F * g.K * g.N * B                          # algorithmic: F=513, N=2T, not the padded tile grid
         names = ['K1 R=V/(W.(s*H))', 'K2 H*=W^T.R/colsum', 'K3 R=V/(W.H)', 'K4a U=R.H^T', 'K4b W update+normalise']
         kern = {}
@@ -146,11 +164,15 @@ def main():
             kern[nm] = {'avg_ms': float(ms[i])}
             if i < 4:
                 kern[nm]['tflops'] = flop_per_launch / (ms[i] * 1e-3) / 1e12
-        achieved = flop_per_launch / (ms[0] * 1e-3) / 1e12
+        achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_kernel<4,1,A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                           'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(ms[0])}
-        out['kernels'] = kern
+                           'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms)}
+        if pmc and pmc.get('files_per_gpu') == B and pmc.get('dictionary_size') == K and a.seconds == 10.0 and a.hop == 256:
+            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (profiles/README.md), gfx950-corrected
+            out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']
+            out['roofline']['traffic_source'] = pmc['source']
+        out['kernels'] = kern             # in-loop event pairs: include ~0.05 ms of event gap per launch
         out['nmf_iteration_ms'] = float(ms.sum())
         out['nmf_gemm_tflops_per_iteration'] = 4 * flop_per_launch / (ms.sum() * 1e-3) / 1e12
 

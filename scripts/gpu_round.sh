@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, smoke, bench, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
 # usage: gpurun --timeout 2400 -- 'bash scripts/gpu_round.sh [tag]'
 TAG=${1:-r01}
-OUT=gpurun_out/$TAG
+OUT=gpurun_out/$TAG; export OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocm-smi --showproductname --showmeminfo vram > $OUT/rocm-smi.txt 2>&1
@@ -20,3 +20,25 @@ echo "rocprof exit $?"; ls -R $OUT/prof | head -20
 find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -30
 # keep the merged-back payload small: drop the raw per-dispatch trace if it is huge
 find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete
+# HBM traffic of the GEMM kernels: separate PMC passes (never combined with the trace domains above)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python bench.py --gpus 1 --steps 1 --warmup 0 --skip-cpu-baseline --skip-roofline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+  echo "pmc $c exit $?"
+  find $OUT/pmc_$c -name "*kernel_trace*" -delete
+done
+python - <<'PY'
+import csv, collections, glob, json, os, sys
+out = os.environ.get('OUT', sys.argv[1] if len(sys.argv) > 1 else '.')
+res = {}
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    files = glob.glob(os.path.join(out, 'pmc_' + c, '*counter_collection.csv'))
+    if not files:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r['Counter_Name'] == c and 'gccnmf_gemm_kernel' in r['Kernel_Name']:
+            agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+    res[c] = {k: {'launches': len(v), 'mean_KB': sum(v) / len(v)} for k, v in agg.items()}
+json.dump(res, open(os.path.join(out, 'pmc_traffic_raw.json'), 'w'), indent=1)
+print(json.dumps(res, indent=1)[:1500])
+PY
