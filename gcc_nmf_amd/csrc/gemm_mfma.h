@@ -274,18 +274,19 @@ __device__ __forceinline__ void gemm_store_operand(const float4 (&r)[U], float* 
 }
 
 // MFMA operand fragments of one k-pair: lane (l31, hh) supplies A[i = l31][k = hh] and B[k = hh][j = l31].
-template <int BM, int BN, bool A_KC, bool B_KC, int LDA, int LDB>
-__device__ __forceinline__ void gemm_read_frags(float (&a)[4], float (&b)[2], const float* __restrict__ sA,
+template <int BM, int BN, bool A_KC, bool B_KC, int LDA, int LDB, int TM>
+__device__ __forceinline__ void gemm_read_frags(float (&a)[TM], float (&b)[2], const float* __restrict__ sA,
                                                 const float* __restrict__ sB, int arow, int bcol, int kk) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = A_KC ? sA[(arow + m * 32) * LDA + kk] : sA[kk * BM + arow + m * 32];
+    for (int m = 0; m < TM; ++m) a[m] = A_KC ? sA[(arow + m * 32) * LDA + kk] : sA[kk * BM + arow + m * 32];
 #pragma unroll
     for (int n = 0; n < 2; ++n) b[n] = B_KC ? sB[(bcol + n * 32) * LDB + kk] : sB[kk * BN + bcol + n * 32];
 }
 
-__device__ __forceinline__ void gemm_mma8(f32x16 (&acc)[4][2], const float (&a)[4], const float (&b)[2]) {
+template <int TM>
+__device__ __forceinline__ void gemm_mma8(f32x16 (&acc)[TM][2], const float (&a)[TM], const float (&b)[2]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
 }
@@ -396,10 +397,11 @@ __device__ __forceinline__ void gemm_epilogue_update_w(const GemmArgs& p, int fi
     }
 }
 
-template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
+template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL, int TM = 4>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p) {
     constexpr int BK = 16;
-    constexpr int BM = WM * 128, BN = WN * 64;
+    constexpr int WT = 32 * TM;             // output rows per wave (TM = 4: 128 x 64 per wave; TM = 1: the small-batch tile)
+    constexpr int BM = WM * WT, BN = WN * 64;
     constexpr int NT = WM * WN * 64;
     constexpr int LDA = A_KC ? (BK + 1) : BM;
     constexpr int LDB = B_KC ? (BK + 1) : BN;
@@ -437,19 +439,19 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int arow = wm * 128 + l31, bcol = wn * 64 + l31;
+    const int arow = wm * WT + l31, bcol = wn * 64 + l31;
 
     const float* __restrict__ A = p.A + file * p.sA;
     const float* __restrict__ B = p.B + file * p.sB;
     const float* __restrict__ bscale = (!B_KC && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
 
-    const bool wave_active = (row0 + wm * 128) < p.M;
+    const bool wave_active = (row0 + wm * WT) < p.M;
     const bool do_tail = TAIL && (tm == 0) && !(p.ablate & 8);
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
 
-    f32x16 acc[4][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -517,17 +519,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
         const float* __restrict__ sT = sB + SB;
         if (wave_active) {
             // software-pipelined fragments: the reads of k-pair p+1 are in flight under the 8 MFMAs of k-pair p
-            float a0[4], b0[2], a1[4], b1[2];
-            gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a0, b0, sA, sB, arow, bcol, hh);
+            float a0[TM], b0[2], a1[TM], b1[2];
+            gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB, TM>(a0, b0, sA, sB, arow, bcol, hh);
 #pragma unroll
             for (int pp = 0; pp < BK / 2; pp += 2) {
-                gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a1, b1, sA, sB, arow, bcol, 2 * (pp + 1) + hh);
+                gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB, TM>(a1, b1, sA, sB, arow, bcol, 2 * (pp + 1) + hh);
                 __builtin_amdgcn_sched_barrier(0);
-                gemm_mma8(acc, a0, b0);
+                gemm_mma8<TM>(acc, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp + 2 < BK / 2) gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB>(a0, b0, sA, sB, arow, bcol, 2 * (pp + 2) + hh);
+                if (pp + 2 < BK / 2) gemm_read_frags<BM, BN, A_KC, B_KC, LDA, LDB, TM>(a0, b0, sA, sB, arow, bcol, 2 * (pp + 2) + hh);
                 __builtin_amdgcn_sched_barrier(0);
-                gemm_mma8(acc, a1, b1);
+                gemm_mma8<TM>(acc, a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -563,14 +565,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
 
     // ---- epilogue: MFMA C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------
     if (EPI == EPI_UPDW) {
-        static_assert(EPI != EPI_UPDW || (WM == 4 && WN == 1 && B_KC), "the fused W update needs the tall tile that owns every row");
-        gemm_epilogue_update_w<TAIL>(p, file, col0, tid, wm, l31, hh, acc, tail_acc, rowsum_acc, smem);
+        static_assert(EPI != EPI_UPDW || (WM == 4 && WN == 1 && TM == 4 && B_KC), "the fused W update needs the tall tile that owns every row");
+        if constexpr (TM == 4) gemm_epilogue_update_w<TAIL>(p, file, col0, tid, wm, l31, hh, acc, tail_acc, rowsum_acc, smem);
         return;
     }
     if (p.ablate & 16) {   // timing experiment: keep the accumulators alive, store one value per lane
         float keep = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -578,8 +580,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
         if (wave_active && keep == 123.456f) p.C[file * p.sC] = keep;
     } else if (wave_active) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            gemm_epilogue_pair<EPI>(p, file, row0 + wm * 128 + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
+        for (int m = 0; m < TM; ++m)
+            gemm_epilogue_pair<EPI>(p, file, row0 + wm * WT + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
     }
     if (TAIL) {
         if (do_tail) {   // block-uniform
@@ -607,9 +609,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     }
 }
 
-template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL>
+template <int WM, int WN, bool A_KC, bool B_KC, int EPI, bool TAIL, int TM = 4>
 static int gccnmf_launch_gemm(GemmArgs a, hipStream_t stream) {
-    constexpr int BM = WM * 128, BN = WN * 64, NT = WM * WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 64, NT = WM * WN * 64;
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
     if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;   // float4 staging
     a.ablate = gccnmf_tune_ablate;
@@ -624,7 +626,7 @@ static int gccnmf_launch_gemm(GemmArgs a, hipStream_t stream) {
         a.xcd_affine = 0;
         grid = a.batch * tiles;
     }
-    hipLaunchKernelGGL((gccnmf_gemm_kernel<WM, WN, A_KC, B_KC, EPI, TAIL>), dim3(grid), dim3(NT), 0, stream, a);
+    hipLaunchKernelGGL((gccnmf_gemm_kernel<WM, WN, A_KC, B_KC, EPI, TAIL, TM>), dim3(grid), dim3(NT), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

@@ -13,6 +13,7 @@
 #include "gemm_mfma.h"
 
 int gccnmf_tune_ablate = 0;
+int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 
 extern "C" {
 int gccnmf_version(void) { return 101; }
@@ -20,6 +21,10 @@ int gccnmf_version(void) { return 101; }
 int gccnmf_set_tuning(int key, int value) {
     if (key == 1) {
         gccnmf_tune_ablate = value;
+        return GCCNMF_OK;
+    }
+    if (key == 2 && value >= 0 && value <= 2) {
+        gccnmf_tune_tile_policy = value;
         return GCCNMF_OK;
     }
     return GCCNMF_ERR_ARG;
@@ -81,34 +86,44 @@ __global__ __launch_bounds__(256) void nmf_prepare_kernel(const float* __restric
 
 // W update + unit-L2 atom normalisation (gccNMFFunctions.py:77,79-80):
 //   Wt = W * (U / rowsumH[k]);  norm[k] = sqrt(sum_f Wt^2);  W = Wt / norm;  hscale = norm;  colsumW = sum_f W
-// grid = batch * Kp/64, 256 threads = 64 atoms x 4 row phases; W and U are read twice (L2-resident
-// 2 x 131 KB per block) instead of keeping F/4 values per thread in registers.
+// grid = batch * Kp/AT, 256 threads = AT atoms x 256/AT row phases; W and U are read twice (L2-resident) instead of
+// keeping F*AT/256 values per thread in registers.  AT = 64 for big batches (256-byte row segments); AT = 16 when the
+// launch would otherwise be a handful of workgroups (single file: 16 -> 64 workgroups, 4x shorter row loops).
+template <int AT>
 __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W, const float* __restrict__ U,
                                                            const float* __restrict__ rowsumH, float* __restrict__ colsumW,
                                                            float* __restrict__ hscale, int F, int Fp, int K, int Kp,
                                                            long sW, long sU, long sVec, long sRowsum) {
+    constexpr int PH = 256 / AT;
     __shared__ float red[256];
-    const int chunks = Kp / 64;
+    __shared__ float s_norm[AT];
+    const int chunks = Kp / AT;
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int k = ch * 64 + c;
+    const int c = threadIdx.x % AT, q = threadIdx.x / AT;
+    const int k = ch * AT + c;
     const bool valid = k < K;          // padded atoms stay exactly zero
     float* Wb = W + b * sW;
     const float* Ub = U + b * sU;
     const float rs = valid ? rowsumH[b * sRowsum + k] : 1.f;
     float ss = 0.f;
     if (valid)
-        for (int f = q; f < F; f += 4) {
+        for (int f = q; f < F; f += PH) {
             const float wt = Wb[(long)f * Kp + k] * (Ub[(long)f * Kp + k] / rs);
             ss = fmaf(wt, wt, ss);
         }
     red[threadIdx.x] = ss;
     __syncthreads();
-    const float norm = sqrtf((red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]));
+    if (q == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < PH; ++j) t += red[c + AT * j];
+        s_norm[c] = sqrtf(t);
+    }
     __syncthreads();
+    const float norm = s_norm[c];
     float cs = 0.f;
     if (valid)
-        for (int f = q; f < F; f += 4) {
+        for (int f = q; f < F; f += PH) {
             const long i = (long)f * Kp + k;
             const float wn = (Wb[i] * (Ub[i] / rs)) / norm;
             Wb[i] = wn;
@@ -117,9 +132,25 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
     red[threadIdx.x] = cs;
     __syncthreads();
     if (q == 0 && valid) {
-        colsumW[b * sVec + k] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < PH; ++j) t += red[c + AT * j];
+        colsumW[b * sVec + k] = t;
         hscale[b * sVec + k] = norm;
     }
+}
+
+static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,
+                           int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s) {
+    if ((long)batch * (Kp / 64) >= 256) {
+        hipLaunchKernelGGL(nmf_update_w_kernel<64>, dim3(batch * (Kp / 64)), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, Fp, K,
+                           Kp, sW, sU, sVec, sRowsum);
+    } else {
+        hipLaunchKernelGGL(nmf_update_w_kernel<16>, dim3(batch * (Kp / 16)), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, Fp, K,
+                           Kp, sW, sU, sVec, sRowsum);
+    }
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
 }
 
 // H[k][:] *= hscale[k].  grid = batch * K rows, 256 threads.  (sScale = 0: one shared scale vector)
@@ -156,9 +187,25 @@ __global__ __launch_bounds__(256) void nmf_reduce_files_kernel(const float* __re
 // ------------------------------------------------------------------------------------------
 // GEMM dispatch: tall <4,1> tile for >128 output rows, wide <1,4> otherwise
 // ------------------------------------------------------------------------------------------
+// Tile choice.  Throughput tile: <4,1> x TM=4 = 512 x 64 per workgroup (128 x 64 per wave).  When the whole launch has
+// fewer tall tiles than the chip has CUs (a single file: 16-40 of them), a workgroup's duration IS the launch duration,
+// so the same 4 waves take a 128 x 64 tile instead (TM = 1: 32 x 64 per wave, 4x shorter, 4x more workgroups).
+// <1,4> serves outputs of <= 128 rows at any batch.
+static bool small_batch_tile(const GemmArgs& a) {
+    if (a.M <= 128 || gccnmf_tune_tile_policy == 1) return false;
+    if (gccnmf_tune_tile_policy == 2) return true;
+    const long tall_tiles = (long)a.batch * gccnmf_ceil_div(a.M, 512) * gccnmf_ceil_div(a.N, 64);
+    return tall_tiles < 256;
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
     const bool tall = a.M > 128;
+    if (small_batch_tile(a)) {
+        if (A_KC) return tail ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, A_KC, 1>(a, s) : gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false, 1>(a, s);
+        if (tail) return GCCNMF_ERR_ARG;
+        return gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false, 1>(a, s);
+    }
     if (A_KC) {
         if (tall) return tail ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false>(a, s);
         return tail ? gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, false>(a, s);
@@ -239,7 +286,11 @@ static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U
 }
 
 // W = normalise(W * (R.H^T) / rowsumH), colsumW, hscale -- K4a and K4b in one launch (tall tile, all F rows in one workgroup)
-static bool can_fuse_w_update(const NmfGeom& g) { return g.Fm > 128 && g.Fm <= 512; }
+static bool can_fuse_w_update(const NmfGeom& g, int batch) {
+    // the fused epilogue needs the tall tile; tiny launches prefer the small-batch tile and the two-launch form
+    if (g.Fm <= 128 || g.Fm > 512 || gccnmf_tune_tile_policy == 2) return false;
+    return gccnmf_tune_tile_policy == 1 || (long)batch * gccnmf_ceil_div(g.K, 64) >= 256;
+}
 
 static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H, float* W, float* colsumW, float* hscale, int batch,
                                int xcd, hipStream_t s) {
@@ -283,13 +334,11 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
         case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
         case 3: return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
         case 4:
-            if (can_fuse_w_update(g) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
+            if (can_fuse_w_update(g, batch) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
             return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
         case 5:
-            if (can_fuse_w_update(g) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
-            hipLaunchKernelGGL(nmf_update_w_kernel, dim3(vec_grid), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, g.F, g.Fp,
-                               g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp);
-            break;
+            if (can_fuse_w_update(g, batch) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
+            return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s);
         case 6:
             hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.Kp, g.Np);
             break;
@@ -384,10 +433,7 @@ int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial,
     hipStream_t s = (hipStream_t)stream;
     NmfGeom g = make_geom(F, N, K);
     SharedWs w = carve_shared(workspace, g, batch);
-    hipLaunchKernelGGL(nmf_update_w_kernel, dim3(g.Kp / 64), dim3(256), 0, s, W, partial, partial + g.sU, w.colsumW, w.hscale,
-                       g.F, g.Fp, g.K, g.Kp, 0L, 0L, 0L, 0L);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
+    return launch_update_w(W, partial, partial + g.sU, w.colsumW, w.hscale, g.F, g.Fp, g.K, g.Kp, 0L, 0L, 0L, 0L, 1, s);
 }
 
 int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream) {

@@ -193,9 +193,18 @@ def test_klnmf_golden_kat(hip):
     assert rel(W, kat['nmf_seed7_W']) < 1e-5 and rel(H, kat['nmf_seed7_H']) < 1e-5
 
 
+@pytest.fixture(params=[0, 1, 2], ids=['tile-auto', 'tile-throughput', 'tile-small'])
+def tile_policy(hip, request):
+    """Both GEMM tile shapes (512x64 throughput tile, 128x64 small-batch tile) at every test size."""
+    lib = hip.lib()
+    assert lib.gccnmf_set_tuning(2, request.param) == 0
+    yield request.param
+    lib.gccnmf_set_tuning(2, 0)
+
+
 @pytest.mark.parametrize('F,N,K,iters,alpha', [(513, 90, 128, 12, 0), (513, 201, 192, 6, 0.3), (257, 77, 40, 10, 0), (200, 333, 300, 5, 0),
                                                (129, 64, 64, 8, 0), (1025, 50, 64, 4, 0)])
-def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha):
+def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha, tile_policy):
     from gcc_nmf_amd.gccNMFFunctions import performKLNMF
     rng = np.random.RandomState(F + N + K)
     V = (np.abs(rng.standard_normal((F, N))) + 0.01).astype(np.float32)

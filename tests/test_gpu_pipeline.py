@@ -77,6 +77,26 @@ def test_hop128_reference_default(dev1):
     assert np.sqrt(np.mean((y[:, :, ::8].astype(np.float64) - g['y_sub']) ** 2)) < 1e-4
 
 
+@pytest.fixture(params=[1, 2], ids=['tile-throughput', 'tile-small'])
+def forced_tile(request):
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    assert lib.gccnmf_set_tuning(2, request.param) == 0
+    yield request.param
+    lib.gccnmf_set_tuning(2, 0)
+
+
+def test_dev1_K1024_both_tiles(dev1, forced_tile):
+    """Config 2 (single dev1 mixture, K = 1024) through each GEMM tile shape explicitly."""
+    x, sr = dev1
+    g = golden('dev1_hop256_K1024')
+    e = engine(x.shape[1], sampleRate=sr, dictionarySize=1024, numIterations=100)
+    y = e.separate(x)[0]
+    assert e.get_tdoa_indexes()[0].tolist() == [47, 72, 107]
+    assert np.mean(e.get_argmax()[0] != g['argmax']) < 1e-3
+    assert np.sqrt(np.mean((y.astype(np.float64) - g['y']) ** 2)) < 1e-4
+
+
 def test_synthetic_against_oracle_stagewise():
     """Seeded synthetic input, every intermediate against the live oracle (ragged T: 9000 samples -> 32 frames)."""
     for n, K, it in [(9000, 24, 7), (30000, 200, 10)]:
