@@ -43,6 +43,8 @@ def parse():
     p.add_argument('--no-xcd-affinity', action='store_true')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
+    p.add_argument('--mode', choices=['separate', 'shared-dictionary'], default='separate',
+                   help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4")
     return p.parse_args()
 
 
@@ -84,6 +86,53 @@ def kernel_timings(e, reps):
     return ms, e0.elapsed_time(e1) / n
 
 
+def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
+    """BASELINE config 4: ONE dictionary for every file of every rank.  Columns (files) are sharded over ranks, W is
+    replicated; each KL-NMF iteration is local GEMMs + one RCCL all-reduce of [num (Fp*Kp) || den (Kp)] floats."""
+    import torch
+    import torch.distributed as dist
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    g, B, K, iters = e.g, e.batch, e.g.K, e.iters
+    e.stft()                                                     # V of this rank's files, on device
+    files = list(range(rank * B, rank * B + B))
+    W0, H0 = shared_initial_factors(g.F, [g.N] * (world * B), K, files, mode='per_file')
+    local = HipSharedNMF.from_device(e.V, g.F, g.N, W0, H0)
+
+    def step():
+        local.reset(W0, H0)
+        train_shared_dictionary(local, iters)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        W = local.W()
+        print(json.dumps({
+            'metric': 'stereo frames/sec, shared-dictionary KL-NMF training (K=%d, %d iters)' % (K, iters),
+            'value': world * B * g.T * a.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': '%d files/GPU, one shared dictionary, all-reduce of %d floats per iteration' %
+                                   (B, local.partial.numel()), 'files_per_gpu': B, 'dictionary_size': K, 'nmf_iterations': iters,
+                       'parallelism': 'columns sharded x%d, W replicated, 1 all-reduce/iteration' % world},
+            'dictionary_finite_unit_norm': bool(np.isfinite(W).all() and np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-4)),
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     import torch
@@ -113,6 +162,9 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
+
+    if a.mode == 'shared-dictionary':
+        return shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier)
 
     for _ in range(a.warmup):
         e.run()
@@ -175,6 +227,22 @@ def main():
         out['kernels'] = kern             # in-loop event pairs: include ~0.05 ms of event gap per launch
         out['nmf_iteration_ms'] = float(ms.sum())
         out['nmf_gemm_tflops_per_iteration'] = 4 * flop_per_launch / (ms.sum() * 1e-3) / 1e12
+
+    if rank == 0 and world == 1:
+        # the same parameters on ONE mixture (BASELINE config 2's shape): latency-bound, small-batch GEMM tile
+        e1 = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=a.hop, numTDOAs=128, microphoneSeparationInMetres=1.0,
+                          numTargets=3, dictionarySize=K, numIterations=iters, batch=1, device='cuda:%d' % local_rank)
+        e1.upload(xs[0])
+        e1.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            e1.run()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / 3
+        out['single_file'] = {'frames_per_s': g.T / dt1, 'ms_per_file': 1e3 * dt1,
+                              # different GEMM tile (launch-size dependent) -> different summation grouping, not bitwise equal
+                              'waveform_rms_vs_in_batch': float(np.sqrt(np.mean((e1.y[0].cpu().numpy().astype(np.float64) - e.y[0].cpu().numpy()) ** 2)))}
 
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline

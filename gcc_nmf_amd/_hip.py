@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgccnmf_hip.so')
+LIB_PATH = os.environ.get('GCCNMF_HIP_LIB') or os.path.join(_HERE, 'libgccnmf_hip.so')     # override: A/B builds only
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 P_INT = ctypes.POINTER(ctypes.c_int)

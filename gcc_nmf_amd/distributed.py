@@ -77,6 +77,35 @@ class HipSharedNMF(object):
         self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self.N, self.K, self.B), dtype=torch.float32, device=dev)
         self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=dev)
 
+    @classmethod
+    def from_device(cls, V_dev, F, N, W0, H0_files, sparsityAlpha=0, epsilon=1e-16):
+        """Shard whose V is already resident ([B][Fp][Np] padded device tensor, e.g. GCCNMFEngine.V after stft())."""
+        self = cls.__new__(cls)
+        self.lib = _hip.lib()
+        self.device = V_dev.device
+        self.B, self.F, self.N, self.K = V_dev.shape[0], int(F), int(N), W0.shape[1]
+        self.alpha, self.eps = float(sparsityAlpha), float(epsilon)
+        g = self.g = Geometry(self.F, 1, self.K)
+        self.Np = -(-self.N // 64) * 64
+        assert tuple(V_dev.shape) == (self.B, g.Fp, self.Np)
+        self.V = V_dev
+        self.Wd = torch.zeros((g.Fp, g.Kp), dtype=torch.float32, device=self.device)
+        self.Hd = torch.zeros((self.B, g.Kp, self.Np), dtype=torch.float32, device=self.device)
+        self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self.N, self.K, self.B), dtype=torch.float32,
+                              device=self.device)
+        self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=self.device)
+        self.reset(W0, H0_files)
+        return self
+
+    def reset(self, W0, H0_files):
+        """(Re)load the initial factors; the padding stays zero."""
+        if not hasattr(self, '_W0d'):
+            g = self.g
+            self._W0d = padded(np.asarray(W0, np.float32), (g.Fp, g.Kp), self.device)
+            self._H0d = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), self.device)
+        self.Wd.copy_(self._W0d)
+        self.Hd.copy_(self._H0d)
+
     def begin(self):
         _hip.check(self.lib.gccnmf_klnmf_shared_begin(_ptr(self.Wd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
                    'gccnmf_klnmf_shared_begin')

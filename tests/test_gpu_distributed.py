@@ -77,3 +77,25 @@ def test_rccl_single_rank_group():
         assert np.linalg.norm(local.W() - Wr) < 1e-4 * np.linalg.norm(Wr)
     finally:
         dist.destroy_process_group()
+
+
+def test_pretraining_cache_roundtrip(tmp_path):
+    """Reference-format dictionary cache (data/pretrainedW/W_<K>.npy, float32 (F,K)) trained on the GPU from the mixtures in
+    DATA_DIR; second load hits the cache; dictionaries agree with the oracle trained on the same matrix."""
+    import shutil
+    from conftest import GOLDEN
+    from gcc_nmf_amd import pretraining as P
+    shutil.copy(os.path.join(GOLDEN, 'data', 'dev1_female3_liverec_130ms_1m_mix.wav'), tmp_path)
+    P.configure(str(tmp_path))
+    W = P.loadPretrainedW(32)
+    path = tmp_path / 'pretrainedW' / 'W_32.npy'
+    assert path.exists() and W.shape == (513, 32) and W.dtype == np.float32
+    assert np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-5)
+    stamp = path.stat().st_mtime_ns
+    assert np.array_equal(P.loadPretrainedW(32), W) and path.stat().st_mtime_ns == stamp      # cached, not retrained
+    V = P.buildTrainingSet(1024, 512)
+    assert V.shape == (513, 2 * 311)
+    Wr, _ = O.performKLNMF(V, 32, 100, 0)
+    assert np.linalg.norm(W - Wr) < 1e-3 * np.linalg.norm(Wr)
+    d = P.getDictionariesW(1024, [32], ordered=True)
+    assert list(d) == ['Pretrained', 'Random'] and d['Pretrained'][32].shape == (513, 32)

@@ -131,3 +131,13 @@ def test_constant_tables():
     Wr, Hr = O.initKLNMF(33, 50, 8)
     assert np.array_equal(W, Wr) and np.array_equal(H, Hr) and W.dtype == np.float32
     assert num_frames(160000, 1024, 256) == 622 and num_frames(160000, 1024, 128) == 1243
+
+
+def test_ordered_dictionary_matches_reference_rule():
+    from gcc_nmf_amd.pretraining import getOrderedDictionary
+    rng = np.random.RandomState(0)
+    W = rng.rand(40, 9).astype(np.float32)
+    Wo = getOrderedDictionary(W)
+    cent = (np.arange(40)[:, None] * Wo).sum(0) / Wo.sum(0)
+    assert Wo.shape == W.shape and np.all(np.diff(cent) >= 0)
+    assert sorted(map(tuple, Wo.T.round(6))) == sorted(map(tuple, W.T.round(6)))       # a permutation of the atoms
