@@ -43,8 +43,8 @@ def parse():
     p.add_argument('--no-xcd-affinity', action='store_true')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
-    p.add_argument('--mode', choices=['separate', 'shared-dictionary'], default='separate',
-                   help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4")
+    p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming'], default='separate',
+                   help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4; 'streaming' = config 5")
     return p.parse_args()
 
 
@@ -133,8 +133,55 @@ def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
         dist.destroy_process_group()
 
 
+def streaming_mode(a):
+    """BASELINE config 5: RT-GCC-NMF, 512-pt window, hop = block = 64 samples (4 ms at 16 kHz), K = 1024 pre-trained-size
+    dictionary, 64 TDOAs, online localisation.  Reports the per-block latency of the fused device call (host block in ->
+    host block out, i.e. including both PCIe copies and the stream sync) and the device-resident rate."""
+    import torch
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF
+    from gcc_nmf_amd.synthetic import synthetic_mixture
+    torch.cuda.set_device(0)
+    ws, hop, B, K, D, sr = 512, 64, 64, a.dictionary_size, 64, 16000
+    rng = np.random.RandomState(0)
+    W = rng.rand(ws // 2 + 1, K).astype(np.float32) + 0.02
+    W /= np.linalg.norm(W, axis=0)
+    p = GCCNMFProcessor(sr, ws, B // hop, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, True, 6, numTDOAs=D)
+    p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    s = StreamingGCCNMF(p, hop, B)
+    x = synthetic_mixture(0, numSamples=sr * 10, delays=(-3, 1, 4))
+    n_blocks = x.shape[1] // B
+    for b in range(50):
+        s.process_block(x[:, b * B:(b + 1) * B])
+    lat = []
+    for b in range(50, n_blocks):
+        t0 = time.perf_counter()
+        s.process_block(x[:, b * B:(b + 1) * B])
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat) * 1e3
+    p.reset()
+    s2 = StreamingGCCNMF(p, hop, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s2.process_stream(x)
+    torch.cuda.synchronize()
+    dev_ms = (time.perf_counter() - t0) * 1e3 / n_blocks
+    block_ms = 1e3 * B / sr
+    print(json.dumps({
+        'metric': 'RT-GCC-NMF p50 per-frame latency (512-pt window, hop 64, K=%d)' % K, 'value': float(np.percentile(lat, 50)), 'unit': 'ms',
+        'n_gpus': 1, 'steps': int(len(lat)), 'warmup': 50, 'ms_per_step': float(lat.mean()), 'higher_is_better': False, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'streaming: 1 frame of 512 samples per 64-sample block, K=%d, 64 TDOAs, online localisation window 6; '
+                               'host block in -> host block out per call' % K, 'window': ws, 'hop': hop, 'block': B},
+        'p99_ms': float(np.percentile(lat, 99)), 'max_ms': float(lat.max()), 'block_duration_ms': block_ms,
+        'real_time_factor_p50': float(np.percentile(lat, 50) / block_ms), 'real_time_factor_p99': float(np.percentile(lat, 99) / block_ms),
+        'device_resident_ms_per_block': dev_ms, 'device_resident_real_time_factor': dev_ms / block_ms,
+        'tracked_tdoa_index': p.targetTDOAIndex}))
+
+
 def main():
     a = parse()
+    if a.mode == 'streaming':
+        return streaming_mode(a)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

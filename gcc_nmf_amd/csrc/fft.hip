@@ -11,41 +11,7 @@
 // Two real signals ride in one complex transform:
 //   forward : z = w*(xL + j xR);  F_L[k] = (Z[k]+conj(Z[N-k]))/2,  F_R[k] = (Z[k]-conj(Z[N-k]))/(2j)
 //   inverse : Z = F_a + j F_b (both Hermitian-extended)  ->  ifft(Z) = y_a + j y_b
-#include "common.h"
-
-#define FFT_TB 8
-#define FFT_NT 256
-#define FFT_ZPAD 9   // row padding (in complex elements) of the per-frame LDS buffers
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// All TB frames advance through the log2(N) radix-2 DIT stages together.  Input must already be in
-// bit-reversed order.  INVERSE uses conjugated twiddles (no 1/N scaling here).
-template <bool INVERSE>
-__device__ __forceinline__ void fft_stages(float2* z, const float2* tw, int N, int logN, int zstride) {
-    const int half_n = N >> 1;
-    for (int s = 1; s <= logN; ++s) {
-        const int half = 1 << (s - 1);
-        const int tw_step = N >> s;
-        for (int idx = threadIdx.x; idx < FFT_TB * half_n; idx += FFT_NT) {
-            const int tb = idx / half_n, bf = idx - tb * half_n;
-            const int grp = bf >> (s - 1), pos = bf & (half - 1);
-            const int i0 = (grp << s) + pos, i1 = i0 + half;
-            float2 w = tw[pos * tw_step];
-            if (INVERSE) w.y = -w.y;
-            float2* zz = z + tb * zstride;
-            const float2 u = zz[i0];
-            const float2 t = cmul(w, zz[i1]);
-            zz[i0] = make_float2(u.x + t.x, u.y + t.y);
-            zz[i1] = make_float2(u.x - t.x, u.y - t.y);
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ int bitrev(int n, int logN) { return (int)(__brev((unsigned)n) >> (32 - logN)); }
+#include "fft_core.h"
 
 // grid = batch * ceil(T / TB); dynamic LDS = (TB*(N+ZPAD) + N/2) float2.
 __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __restrict__ x, long x_stride, int n_samples, int N,
@@ -185,12 +151,6 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     float acc = 0.f;
     for (int t = t_lo; t <= t_hi; ++t) acc = acc + fr[(long)t * N + (s - t * hop)];
     y[sig * L + m] = acc * gain;
-}
-
-static int ilog2_exact(int n) {
-    int l = 0;
-    while ((1 << l) < n) ++l;
-    return ((1 << l) == n) ? l : -1;
 }
 
 extern "C" {

@@ -1,0 +1,357 @@
+// Streaming (real-time) GCC-NMF frame processor on gfx950 -- SURVEY.md section 8f #1 and #4.
+// Reference: gccNMF/realtime/gccNMFProcessor.py:201-270 (the Theano graph + processFrames) and
+// gccNMF/realtime/utils.py:72-118 (OverlapAddProcessor), :34-70 (history ring).
+//
+// One block of `blockSize` new stereo samples per call; Tc = blockSize/hopSize analysis windows per call.
+// Latency-bound, not throughput-bound: everything is sized so that a call is six short launches on one stream and the
+// only host traffic is the new block in and the finished block out.
+//   rt_shift      8-block input / output buffers move one block left, new samples appended          (utils.py:99-103)
+//   rt_frames     sqrt-hamming window, both channels in one packed complex FFT, X and PHAT coherence (processor :202,:253)
+//   rt_gccnmf     S[tau,k] = sum_f Re(C[f] e^{-j w tau}) W[f,k] on the matrix cores, arg-max over tau,
+//                 soft / boxcar coefficient mask around the tracked target TDOA                      (:254,:259-265)
+//   rt_tfmask     tfMask[f] = sum_k W[f,k] HMask[k] / sum_k W[f,k];  Y = tfMask * X                  (:267-269,:209)
+//   rt_synth      packed inverse FFT, synthesis window, overlap-add, hand out the block two blocks old (:231, utils.py:113-116)
+//   rt_localize   gccPHAT[tau] = nanmean_f G, history ring, target = argmax nanmean(last L columns)   (:214-222)
+// NaN semantics follow the reference here (a zero-magnitude bin makes the frame's GCC-NMF scores NaN and its arg-max 0;
+// nanmean skips it), because the localisation history depends on them.
+#include "fft_core.h"
+
+typedef float rt_f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- rt_shift: single workgroup, in-place left shift by B of both 8-block buffers ---------------------------
+__global__ __launch_bounds__(1024) void rt_shift_kernel(float* __restrict__ in_ring, float* __restrict__ out_ring,
+                                                        const float* __restrict__ block_in, int B, int ring) {
+    // ring = 8*B samples per channel, 2 channels; every thread first loads everything it will store
+    const int total = 2 * ring;
+    float vin[8], vout[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int i = threadIdx.x + 1024 * n;
+        vin[n] = vout[n] = 0.f;
+        if (i < total) {
+            const int c = i / ring, s = i - c * ring;
+            vin[n] = (s + B < ring) ? in_ring[c * ring + s + B] : block_in[c * B + (s + B - ring)];
+            vout[n] = (s + B < ring) ? out_ring[c * ring + s + B] : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int i = threadIdx.x + 1024 * n;
+        if (i < total) {
+            in_ring[i] = vin[n];
+            out_ring[i] = vout[n];
+        }
+    }
+}
+
+// ---- rt_frames: grid = Tc, one analysis window per workgroup ----------------------------------------------------
+__global__ __launch_bounds__(FFT_NT) void rt_frames_kernel(const float* __restrict__ in_ring, int ring, int N, int logN, int start0,
+                                                           int start_step, int Tc, const float* __restrict__ window,
+                                                           const float2* __restrict__ twiddle, float2* __restrict__ X,
+                                                           float2* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) float2 rt_smem[];
+    float2* z = rt_smem;
+    float2* tw = rt_smem + N;
+    const int t = blockIdx.x;
+    const int F = N / 2 + 1;
+    const int start = start0 + t * start_step;            // ring mode: utils.py:105; frames mode: t * N
+    for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
+    for (int n = threadIdx.x; n < N; n += FFT_NT) {
+        const float w = window[n];
+        z[bitrev(n, logN)] = make_float2(w * in_ring[start + n], w * in_ring[ring + start + n]);
+    }
+    __syncthreads();
+    fft_stages<false, 1>(z, tw, N, logN, N);
+    for (int f = threadIdx.x; f < F; f += FFT_NT) {
+        const float2 zk = z[f], zn = z[(N - f) & (N - 1)];
+        const float2 XL = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));     // rfft, NOT conjugated (:202)
+        const float2 XR = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        X[(long)f * Tc + t] = XL;
+        X[((long)F + f) * Tc + t] = XR;
+        const float aL = hypotf(XL.x, XL.y), aR = hypotf(XR.x, XR.y);
+        float re = XL.x * XR.x + XL.y * XR.y, im = XL.y * XR.x - XL.x * XR.y;
+        C[(long)f * Tc + t] = make_float2(re / aL / aR, im / aL / aR);                   // 0/0 -> NaN like the reference (:253)
+    }
+}
+
+// ---- rt_gccnmf: grid = (Kp/64, Tc); 4 waves = 2 tau-tile lanes x 2 atom tiles of 32 ------------------------
+// MFMA 32x32x2: A[i = tau][k = f] = G[f][tau] built on the fly from the steering tables, B[k = f][j = atom] = W[f][atom].
+__global__ __launch_bounds__(256) void rt_gccnmf_kernel(const float2* __restrict__ C, const float* __restrict__ cosT,
+                                                        const float* __restrict__ sinT, const float* __restrict__ W, int F, int K,
+                                                        int Kp, int D, int Dp, int Tc, const float* __restrict__ target,
+                                                        int target_mode, float* __restrict__ HMask, int* __restrict__ argmaxTDOA) {
+    __shared__ float s_val[2][64];
+    __shared__ int s_idx[2][64];
+    const int t = blockIdx.y, k0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int kt = wave & 1, tlane = wave >> 1;
+    const int atom = k0 + kt * 32 + l31;
+    float best_val = -INFINITY;
+    int best_idx = 0;
+    const int steps = (F + 1) / 2;
+    for (int tt = tlane; tt * 32 < Dp; tt += 2) {
+        rt_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int tau = tt * 32 + l31;
+#pragma unroll 4
+        for (int p = 0; p < steps; ++p) {
+            const int f = 2 * p + hh;
+            float a = 0.f, b = 0.f;
+            if (f < F) {
+                const float2 c = C[(long)f * Tc + t];
+                a = c.x * cosT[(long)f * Dp + tau] + c.y * sinT[(long)f * Dp + tau];
+                b = W[(long)f * Kp + atom];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        // arg-max over this tile's 32 TDOAs for the lane's atom: rows (r&3) + 8*(r>>2) + 4*hh, ascending within a lane
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float v = acc[r];
+            if (row < D && (v > best_val || (v == best_val && row < best_idx))) {
+                best_val = v;
+                best_idx = row;
+            }
+        }
+    }
+    // other row half of the same wave, then the other tau-lane wave of the same atom tile
+    {
+        const float ov = __shfl_xor(best_val, 32);
+        const int oi = __shfl_xor(best_idx, 32);
+        if (ov > best_val || (ov == best_val && oi < best_idx)) {
+            best_val = ov;
+            best_idx = oi;
+        }
+    }
+    if (hh == 0) {
+        s_val[tlane][kt * 32 + l31] = best_val;
+        s_idx[tlane][kt * 32 + l31] = best_idx;
+    }
+    __syncthreads();
+    if (tid < 64 && (k0 + tid) < K) {
+        float v = s_val[0][tid];
+        int i = s_idx[0][tid];
+        const float v1 = s_val[1][tid];
+        const int i1 = s_idx[1][tid];
+        if (v1 > v || (v1 == v && i1 < i)) {
+            v = v1;
+            i = i1;
+        }
+        if (!(v > -INFINITY)) i = 0;          // every score NaN (or D == 0): numpy.argmax of an all-NaN column is 0
+        const float tgt = target[0], eps = target[1], beta = target[2], nf = target[3];
+        const float dist = fabsf((float)i - tgt);
+        float m;
+        if (target_mode == 0)
+            m = dist < eps ? 1.f : 0.f;                                   // TARGET_MODE_BOXCAR (:263)
+        else
+            m = expf(-powf(dist / eps, beta)) / (1.f + nf) + nf;          // TARGET_MODE_WINDOW_FUNCTION (:265)
+        HMask[(long)(k0 + tid) * Tc + t] = m;
+        if (argmaxTDOA) argmaxTDOA[(long)(k0 + tid) * Tc + t] = i;
+    }
+}
+
+// ---- rt_tfmask: one wave per frequency row; grid = ceil(F/4) ------------------------------------------------------
+__global__ __launch_bounds__(256) void rt_tfmask_kernel(const float* __restrict__ W, const float* __restrict__ HMask, int F, int K,
+                                                        int Kp, int Tc, const float2* __restrict__ X, float2* __restrict__ Y, float* __restrict__ tfMask) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + wave;
+    if (f >= F) return;
+    const float* Wr = W + (long)f * Kp;
+    float rec = 0.f;
+    for (int k = lane; k < K; k += 64) rec += Wr[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rec += __shfl_xor(rec, o);
+    for (int t = 0; t < Tc; ++t) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], HMask[(long)k * Tc + t], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const float m = s / rec;
+            tfMask[(long)f * Tc + t] = m;
+            const float2 a = X[(long)f * Tc + t], b = X[((long)F + f) * Tc + t];
+            Y[(long)f * Tc + t] = make_float2(m * a.x, m * a.y);
+            Y[((long)F + f) * Tc + t] = make_float2(m * b.x, m * b.y);
+        }
+    }
+}
+
+// ---- rt_synth: single workgroup; frames in order (their output ranges overlap) ----------------------------------------
+__global__ __launch_bounds__(FFT_NT) void rt_synth_kernel(const float2* __restrict__ Y, int N, int logN, int start0, int start_step,
+                                                          int accumulate, int Tc, int ring, int B, const float* __restrict__ window,
+                                                          const float2* __restrict__ twiddle, float* __restrict__ out_ring,
+                                                          float* __restrict__ block_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 rt_smem[];
+    float2* z = rt_smem;
+    float2* tw = rt_smem + N;
+    const int F = N / 2 + 1;
+    const float invN = 1.f / (float)N;
+    for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
+    for (int t = 0; t < Tc; ++t) {
+        __syncthreads();
+        for (int f = threadIdx.x; f < F; f += FFT_NT) {
+            float2 a = Y[(long)f * Tc + t], b = Y[((long)F + f) * Tc + t];
+            if (f == 0 || f == N / 2) {      // numpy.fft.irfft ignores the imaginary part of DC and Nyquist
+                a.y = 0.f;
+                b.y = 0.f;
+            }
+            z[bitrev(f, logN)] = make_float2(a.x - b.y, a.y + b.x);
+            if (f != 0 && f != N / 2) z[bitrev(N - f, logN)] = make_float2(a.x + b.y, b.x - a.y);
+        }
+        __syncthreads();
+        fft_stages<true, 1>(z, tw, N, logN, N);
+        const int start = start0 + t * start_step;
+        for (int n = threadIdx.x; n < N; n += FFT_NT) {
+            const float w = window[n];
+            const float ya = w * (z[n].x * invN), yb = w * (z[n].y * invN);
+            if (accumulate) {                    // overlap-add into the output buffer (utils.py:113-114)
+                out_ring[start + n] += ya;
+                out_ring[ring + start + n] += yb;
+            } else {                             // frames mode: the processed frames themselves (:231)
+                out_ring[start + n] = ya;
+                out_ring[ring + start + n] = yb;
+            }
+        }
+    }
+    if (!accumulate) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * B; i += FFT_NT) {
+        const int c = i / B, s = i - c * B;
+        block_out[i] = out_ring[c * ring + ring - 3 * B + s];                         // utils.py:116
+    }
+}
+
+// ---- rt_localize: single workgroup of 1024 threads = Dq TDOAs x 1024/Dq frequency phases ---------------------------
+// hist is a [D][Lh] float ring with write position hist_pos[0]; target[0] is updated for the NEXT block (:216-222).
+__global__ __launch_bounds__(1024) void rt_localize_kernel(const float2* __restrict__ C, const float* __restrict__ cosT,
+                                                           const float* __restrict__ sinT, int F, int D, int Dp, int Dq, int Tc,
+                                                           float* __restrict__ hist, int Lh, int* __restrict__ hist_pos,
+                                                           int loc_enabled, int loc_window, float* __restrict__ target,
+                                                           float* __restrict__ gccphat_out) {
+    __shared__ float s_sum[1024];
+    __shared__ int s_cnt[1024];
+    const int tau = threadIdx.x % Dq, g = threadIdx.x / Dq, G = 1024 / Dq;
+    int pos = hist_pos[0];
+    for (int t = 0; t < Tc; ++t) {
+        float s = 0.f;
+        int cnt = 0;
+        if (tau < D)
+            for (int f = g; f < F; f += G) {
+                const float2 c = C[(long)f * Tc + t];
+                const float v = c.x * cosT[(long)f * Dp + tau] + c.y * sinT[(long)f * Dp + tau];
+                if (v == v) {
+                    s += v;
+                    ++cnt;
+                }
+            }
+        s_sum[threadIdx.x] = s;
+        s_cnt[threadIdx.x] = cnt;
+        __syncthreads();
+        if (g == 0 && tau < D) {
+            float st = 0.f;
+            int ct = 0;
+            for (int j = 0; j < G; ++j) {
+                st += s_sum[j * Dq + tau];
+                ct += s_cnt[j * Dq + tau];
+            }
+            const float m = ct ? st / (float)ct : NAN;                                    // numpy.nanmean over f (:214)
+            hist[(long)tau * Lh + pos] = m;
+            if (gccphat_out) gccphat_out[(long)tau * Tc + t] = m;
+        }
+        __syncthreads();
+        pos = (pos + 1) % Lh;
+    }
+    if (loc_enabled) {
+        if (g == 0) {
+            float m = NAN;
+            if (tau < D) {
+                float s = 0.f;
+                int cnt = 0;
+                for (int j = 1; j <= loc_window; ++j) {                                   // the last L columns
+                    const float v = hist[(long)tau * Lh + ((pos - j) % Lh + Lh) % Lh];
+                    if (v == v) {
+                        s += v;
+                        ++cnt;
+                    }
+                }
+                m = cnt ? s / (float)cnt : NAN;
+            }
+            s_sum[tau] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // numpy.argmax: NaN counts as the maximum, first occurrence wins
+            int best = 0;
+            bool best_nan = s_sum[0] != s_sum[0];
+            for (int i = 1; i < D && !best_nan; ++i) {
+                const float v = s_sum[i];
+                if (v != v) {
+                    best = i;
+                    best_nan = true;
+                } else if (v > s_sum[best]) {
+                    best = i;
+                }
+            }
+            target[0] = (float)best;
+        }
+    }
+    if (threadIdx.x == 0) hist_pos[0] = pos;
+}
+
+extern "C" {
+
+// Every buffer is passed explicitly (allocation lives with the host, gcc_nmf_amd/realtime.py).
+//   frames_mode = 0: streaming.  block_in [2][B] -> 8-block input buffer -> Tc windows -> ... -> overlap-add -> block_out [2][B]
+//   frames_mode = 1: the reference's GCCNMFProcessor.processFrames on its own: in_ring = windowed-sample frames [2][Tc][N]
+//                    in, out_ring = processed frames [2][Tc][N] out, no shift / overlap-add (block_in, block_out unused).
+int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
+                            float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
+                            float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
+                            const float* twiddle, int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp,
+                            int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
+                            int localization_window, int frames_mode, void* stream) {
+    const int logN = ilog2_exact(windowSize);
+    if (!in_ring || !out_ring || !X || !Y || !C || !HMask || !tfMask || !hist || !hist_pos || !target || !W || !cosT || !sinT ||
+        !window || !twiddle || (!frames_mode && (!block_in || !block_out)))
+        return GCCNMF_ERR_ARG;
+    if (logN < 6 || logN > 12 || hopSize < 1 || blockSize < hopSize || blockSize % hopSize || K < 1 || Kp % 64 || Kp < K || D < 1 ||
+        D > 1024 || Dp % 32 || Dp < D || numTDOAHistory < 1 || localization_window < 1 || localization_window > numTDOAHistory)
+        return GCCNMF_ERR_ARG;
+    const int Tc = blockSize / hopSize, F = windowSize / 2 + 1;
+    const int ring = frames_mode ? Tc * windowSize : 8 * blockSize;
+    if (!frames_mode && (ring < windowSize + (Tc - 1) * hopSize || 2 * ring > 8 * 1024)) return GCCNMF_ERR_UNSUPPORTED;
+    const int start0 = frames_mode ? 0 : ring - windowSize - (Tc - 1) * hopSize;
+    const int start_step = frames_mode ? windowSize : hopSize;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = sizeof(float2) * (windowSize + windowSize / 2);
+    if (!frames_mode) {
+        hipLaunchKernelGGL(rt_shift_kernel, dim3(1), dim3(1024), 0, s, in_ring, out_ring, block_in, blockSize, ring);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(rt_frames_kernel, dim3(Tc), dim3(FFT_NT), lds, s, in_ring, ring, windowSize, logN, start0, start_step, Tc,
+                       window, (const float2*)twiddle, (float2*)X, (float2*)C);
+    GCCNMF_CHECK_LAUNCH();
+    if (separation_enabled) {
+        hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 64, Tc), dim3(256), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
+                           target, target_mode, HMask, argmaxTDOA);
+        GCCNMF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(rt_tfmask_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, HMask, F, K, Kp, Tc, (const float2*)X,
+                           (float2*)Y, tfMask);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(rt_synth_kernel, dim3(1), dim3(FFT_NT), lds, s, (const float2*)(separation_enabled ? Y : X), windowSize, logN,
+                       start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, window, (const float2*)twiddle, out_ring, block_out);
+    GCCNMF_CHECK_LAUNCH();
+    int Dq = 64;
+    while (Dq < D) Dq *= 2;                 // power of two so that 1024 % Dq == 0
+    hipLaunchKernelGGL(rt_localize_kernel, dim3(1), dim3(1024), 0, s, (const float2*)C, cosT, sinT, F, D, Dp, Dq, Tc, hist,
+                       numTDOAHistory, hist_pos, localization_enabled, localization_window, target, gccphat);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+}  // extern "C"

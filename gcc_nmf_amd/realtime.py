@@ -1,0 +1,147 @@
+"""Streaming (real-time) GCC-NMF on MI355X -- the reference's ``gccNMF/realtime/gccNMFProcessor.py`` frame processor
+(a Theano graph there) and ``gccNMF/realtime/utils.py`` overlap-add, as one C-ABI call per audio block
+(``gccnmf_rt_process_block``, csrc/rt.hip).
+
+``GCCNMFProcessor`` keeps the reference's constructor arguments, attributes and methods
+(``processFrames(windowedSamples)``, ``setTargetTDOARange``, ``reset``); ``StreamingGCCNMF`` is the fused
+block-in / block-out path (input ring, frames, mask, synthesis, overlap-add and TDOA tracking all on device).
+No CPU fallback: without the library / a device the constructor raises ``HipLibraryError``.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+from .engine import padded, fft_twiddles, _ptr, _stream
+
+SPEED_OF_SOUND_IN_METRES_PER_SECOND = 340.29
+TARGET_MODE_BOXCAR = 0                   # gccNMFProcessor.py:35-37
+TARGET_MODE_MULTIPLE = 1
+TARGET_MODE_WINDOW_FUNCTION = 2
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _hip.HipLibraryError('no ROCm device visible: gcc_nmf_amd has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class GCCNMFProcessor(object):
+    """gccNMF/realtime/gccNMFProcessor.py:167-275.  ``dictionariesW[dictionaryType][dictionarySize]`` is the (F, K) float32
+    dictionary (:241).  ``numTDOAs`` is an attribute the reference receives through its parameter queue before ``reset()``;
+    here it is also a constructor keyword."""
+
+    def __init__(self, sampleRate, windowSize, numTimePerChunk, dictionariesW, dictionaryType, dictionarySize, numHUpdates,
+                 microphoneSeparationInMetres, localizationEnabled, localizationWindowSize, gccPHATHistory=None, tdoaHistory=None,
+                 inputSpectrogramHistory=None, outputSpectrogramHistory=None, coefficientMaskHistories=None, numTDOAs=64,
+                 numTDOAHistory=128):
+        self.lib = _hip.lib()
+        self.device = _device()
+        self.sampleRate, self.windowSize, self.numTimePerChunk = sampleRate, int(windowSize), int(numTimePerChunk)
+        self.dictionariesW, self.dictionaryType, self.dictionarySize = dictionariesW, dictionaryType, dictionarySize
+        self.numHUpdates = numHUpdates                    # accepted and unused, exactly as in the reference (:168)
+        self.microphoneSeparationInMetres = microphoneSeparationInMetres
+        self.localizationEnabled, self.localizationWindowSize = localizationEnabled, int(localizationWindowSize)
+        self.numTDOAs, self.numTDOAHistory = int(numTDOAs), int(numTDOAHistory)
+        self.separationEnabled = True
+        self.targetMode = TARGET_MODE_WINDOW_FUNCTION
+        self.windowFunction = np.sqrt(np.hamming(self.windowSize).astype(np.float32))[:, np.newaxis]      # :186
+        self.synthesisWindowFunction = self.windowFunction
+        self._target_host = np.array([10.0, 2.0, 1.0, 0.0], np.float32)                                   # :195-198
+        self.reset()
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def reset(self):
+        """:233-270 (buildTheanoFunctions): tables and buffers for the current dictionary / TDOA grid."""
+        dev = self.device
+        self.W = np.asarray(self.dictionariesW[self.dictionaryType][self.dictionarySize], np.float32)
+        self.numFrequencies, self.numAtom = self.W.shape
+        if self.numFrequencies != self.windowSize // 2 + 1:
+            raise ValueError('dictionary has %d rows, window size %d needs %d' % (self.numFrequencies, self.windowSize, self.windowSize // 2 + 1))
+        F, K, D, Tc = self.numFrequencies, self.numAtom, self.numTDOAs, self.numTimePerChunk
+        self.Kp, self.Dp = -(-K // 64) * 64, -(-D // 32) * 32
+        self.frequenciesInHz = np.linspace(0, self.sampleRate / 2, F).astype(np.float32)                 # :245
+        self.maxTDOA = self.microphoneSeparationInMetres / SPEED_OF_SOUND_IN_METRES_PER_SECOND
+        self.hypothesisTDOAs = np.linspace(-self.maxTDOA, self.maxTDOA, D).astype(np.float32)            # :247
+        self.expJOmegaTau = np.exp(np.outer(self.frequenciesInHz, -(2j * np.pi) * self.hypothesisTDOAs)).astype(np.complex64)
+        z = lambda *shape, **kw: torch.zeros(shape, dtype=kw.get('dtype', torch.float32), device=dev)
+        self.dW = padded(self.W, (F, self.Kp), dev)
+        self.dCos = padded(np.ascontiguousarray(self.expJOmegaTau.real), (F, self.Dp), dev)
+        self.dSin = padded(np.ascontiguousarray(-self.expJOmegaTau.imag), (F, self.Dp), dev)
+        self.dWindow = torch.from_numpy(np.ascontiguousarray(self.windowFunction[:, 0])).to(dev)
+        self.dTwiddle = torch.from_numpy(fft_twiddles(self.windowSize)).to(dev)
+        self.dX, self.dY, self.dC = z(2, F, Tc, 2), z(2, F, Tc, 2), z(F, Tc, 2)
+        self.dHMask, self.dArgmax = z(self.Kp, Tc), z(self.Kp, Tc, dtype=torch.int32)
+        self.dTfMask, self.dGccPhat = z(F, Tc), z(D, Tc)
+        self.dHist, self.dHistPos = z(D, self.numTDOAHistory), z(1, dtype=torch.int32)
+        self.dTarget = torch.from_numpy(self._target_host.copy()).to(dev)
+        self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
+
+    def setTargetTDOARange(self, targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor):
+        """:272-275"""
+        self._target_host = np.array([targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor], np.float32)
+        self.dTarget.copy_(torch.from_numpy(self._target_host))
+
+    @property
+    def targetTDOAIndex(self):
+        return float(self.dTarget[0].item())
+
+    def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode):
+        _hip.check(self.lib.gccnmf_rt_process_block(
+            _ptr(block_in), _ptr(block_out), _ptr(in_ring), _ptr(out_ring), _ptr(self.dX), _ptr(self.dY), _ptr(self.dC), _ptr(self.dHMask),
+            _ptr(self.dArgmax), _ptr(self.dTfMask), _ptr(self.dHist), _ptr(self.dHistPos), _ptr(self.dTarget), _ptr(self.dGccPhat),
+            _ptr(self.dW), _ptr(self.dCos), _ptr(self.dSin), _ptr(self.dWindow), _ptr(self.dTwiddle), self.windowSize, hop, block,
+            self.numAtom, self.Kp, self.numTDOAs, self.Dp, self.numTDOAHistory, int(self.targetMode), int(bool(self.separationEnabled)),
+            int(bool(self.localizationEnabled)), self.localizationWindowSize, frames_mode, _stream()), 'gccnmf_rt_process_block')
+
+    def processFrames(self, windowedSamples):
+        """:201-231.  (2, windowSize, Tc) windowed-sample frames -> (2, windowSize, Tc) processed frames (float32)."""
+        ws = np.asarray(windowedSamples, np.float32)
+        Tc = self.numTimePerChunk
+        if ws.shape != (2, self.windowSize, Tc):
+            raise ValueError('expected windowedSamples of shape %s, got %s' % ((2, self.windowSize, Tc), ws.shape))
+        self.dFramesIn.copy_(torch.from_numpy(np.ascontiguousarray(ws.transpose(0, 2, 1))))
+        # hop = windowSize, block = Tc * windowSize describes Tc back-to-back frames to the kernels' start0/step arithmetic
+        self._call(None, None, self.dFramesIn, self.dFramesOut, self.windowSize, Tc * self.windowSize, 1)
+        return self.dFramesOut.cpu().numpy().transpose(0, 2, 1)
+
+    # ---- device results of the last call, in the reference's shapes --------------------------------------------------
+    def intermediates(self):
+        F, K, D = self.numFrequencies, self.numAtom, self.numTDOAs
+        return dict(X=torch.view_as_complex(self.dX).cpu().numpy(), C=torch.view_as_complex(self.dC).cpu().numpy(),
+                    HMask=self.dHMask[:K].cpu().numpy(), argmaxTDOA=self.dArgmax[:K].cpu().numpy(), tfMask=self.dTfMask.cpu().numpy(),
+                    gccPHAT=self.dGccPhat.cpu().numpy(), targetTDOAIndex=self.targetTDOAIndex)
+
+
+class StreamingGCCNMF(object):
+    """``OverlapAddProcessor.processFrames(GCCNMFProcessor.processFrames)`` (utils.py:99-116) as one device call per block:
+    ``process_block((2, blockSize)) -> (2, blockSize)``, output delayed by two blocks like the reference."""
+
+    def __init__(self, processor, hopSize, blockSize):
+        if blockSize % hopSize or blockSize // hopSize != processor.numTimePerChunk:
+            raise ValueError('blockSize/hopSize must equal the processor\'s numTimePerChunk')
+        self.p, self.hopSize, self.blockSize = processor, int(hopSize), int(blockSize)
+        dev = processor.device
+        self.in_ring = torch.zeros((2, 8 * blockSize), dtype=torch.float32, device=dev)
+        self.out_ring = torch.zeros((2, 8 * blockSize), dtype=torch.float32, device=dev)
+        self.block_in = torch.zeros((2, blockSize), dtype=torch.float32, device=dev)
+        self.block_out = torch.zeros((2, blockSize), dtype=torch.float32, device=dev)
+
+    def process_block_device(self, block_in, block_out):
+        """Device tensors in/out, asynchronous on the current stream (what a capture/playback loop would call)."""
+        self.p._call(block_in, block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 0)
+
+    def process_block(self, block):
+        self.block_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))
+        self.process_block_device(self.block_in, self.block_out)
+        return self.block_out.cpu().numpy()
+
+    def process_stream(self, stereoSamples):
+        """(2, n) -> (2, n_blocks*blockSize); the whole signal is uploaded once, every block is one device call."""
+        x = torch.from_numpy(np.ascontiguousarray(stereoSamples, dtype=np.float32)).to(self.p.device)
+        B = self.blockSize
+        n_blocks = x.shape[1] // B
+        xb = x[:, :n_blocks * B].reshape(2, n_blocks, B).permute(1, 0, 2).contiguous()      # [block][2][B]
+        out = torch.zeros((n_blocks, 2, B), dtype=torch.float32, device=self.p.device)
+        for b in range(n_blocks):
+            self.process_block_device(xb[b], out[b])
+        return out.permute(1, 0, 2).reshape(2, n_blocks * B).cpu().numpy()

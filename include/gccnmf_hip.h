@@ -146,6 +146,29 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
 
+/* Streaming (real-time) GCC-NMF: one block of `blockSize` new stereo samples per call, Tc = blockSize/hopSize analysis
+ * windows.  Replaces GCCNMFProcessor.processFrames (gccNMF/realtime/gccNMFProcessor.py:201-270, a Theano graph in the
+ * reference) together with OverlapAddProcessor.processFrames (gccNMF/realtime/utils.py:99-116) and the gccPHAT history /
+ * online localisation (:214-222, utils.py:34-70).  Six launches on `stream`, no host synchronisation.
+ *   block_in / block_out [2][blockSize]            new samples in, the block two blocks old out (utils.py:116)
+ *   in_ring / out_ring   [2][8*blockSize]          state: the reference's 8-block buffers
+ *   X, Y [2][F][Tc] complex, C [F][Tc] complex     rfft (not conjugated), masked spectrogram, PHAT coherence
+ *   HMask [Kp][Tc], argmaxTDOA [Kp][Tc] (or NULL), tfMask [F][Tc], gccphat [D][Tc] (or NULL)
+ *   hist [D][numTDOAHistory] + hist_pos [1]        state: gccPHAT history ring
+ *   target [4]                                     state: {targetTDOAIndex, epsilon, beta, noiseFloor}; index rewritten by
+ *                                                  the localisation for the NEXT block
+ *   W [F][Kp]; cosT / sinT [F][Dp] = Re / -Im of exp(-2j pi f tau) (Dp = round_up(D,32), zero padded), float32 grids as
+ *   in :245-248; window [windowSize] = sqrt(hamming) (:186); twiddle as for gccnmf_stft_stereo
+ *   target_mode 0 = boxcar (:263), 2 = window function (:265)
+ *   frames_mode 1 = processFrames alone: in_ring holds windowed-sample frames [2][Tc][windowSize], out_ring receives the
+ *   processed frames, no shift / overlap-add. */
+int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y,
+                            float* C, float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
+                            float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
+                            const float* twiddle, int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp,
+                            int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
+                            int localization_window, int frames_mode, void* stream);
+
 /* Diagnostics: a pure v_mfma_f32_32x32x2_f32 loop (blocks x 4 waves x iters x 8 instructions, 2*32*32*2 flop each):
  * the matrix-pipe rate this box sustains, quoted next to the roofline fractions. */
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);

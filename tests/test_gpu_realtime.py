@@ -1,0 +1,93 @@
+"""-m gpu: the streaming GCC-NMF frame processor (csrc/rt.hip via gcc_nmf_amd.realtime) against the NumPy oracle of
+gccNMF/realtime/gccNMFProcessor.py + utils.py (oracle/rt_oracle.py)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import gccnmf_oracle as O
+from oracle import rt_oracle as R
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+def make(ws, K, D, Tc, seed=0, loc=True, L=6):
+    from gcc_nmf_amd.realtime import GCCNMFProcessor
+    rng = np.random.RandomState(seed)
+    W = (rng.rand(ws // 2 + 1, K).astype(np.float32) + 0.02)
+    W /= np.linalg.norm(W, axis=0)
+    dev = GCCNMFProcessor(16000, ws, Tc, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, loc, L, numTDOAs=D)
+    ora = R.GCCNMFProcessorOracle(16000, ws, Tc, W, 0.1, D, localizationEnabled=loc, localizationWindowSize=L)
+    return dev, ora, rng
+
+
+@pytest.mark.parametrize('ws,K,D,Tc', [(1024, 64, 64, 1), (512, 200, 40, 4), (1024, 1024, 64, 2), (256, 96, 33, 8)])
+def test_process_frames_matches_oracle(ws, K, D, Tc):
+    dev, ora, rng = make(ws, K, D, Tc)
+    for mode, params in [(2, (9.6, 5.0, 2.0, 0.0)), (2, (20.0, 3.0, 1.0, 0.2)), (0, (12.0, 4.0, 1.0, 0.0))]:
+        dev.targetMode = ora.targetMode = mode
+        dev.localizationEnabled = ora.localizationEnabled = False
+        dev.setTargetTDOARange(*params)
+        ora.setTargetTDOARange(*params)
+        frames = (rng.standard_normal((2, ws, Tc)) * 0.1).astype(np.float32)
+        out = dev.processFrames(frames)
+        ref, im = ora.processFrames(frames, return_intermediates=True)
+        d = dev.intermediates()
+        assert np.abs(d['X'] - im['X']).max() < 1e-5 * np.abs(im['X']).max()
+        strong = np.minimum(np.abs(im['X'][0]), np.abs(im['X'][1])) > 1e-2 * np.abs(im['X']).max()
+        assert np.abs(d['C'] - im['C'])[strong].max() < 2e-3
+        assert np.mean(d['argmaxTDOA'] != im['argmaxTDOA']) < 5e-3                 # near-ties of f32 vs f32-BLAS scores only
+        same = d['argmaxTDOA'] == im['argmaxTDOA']
+        assert np.abs(d['HMask'] - im['HMask'])[same].max() < 1e-5
+        assert np.abs(d['gccPHAT'] - im['gccPHAT']).max() < 1e-3
+        if same.all():
+            assert np.abs(d['tfMask'] - im['tfMask']).max() < 1e-4
+            assert np.abs(out - ref).max() < 1e-4 * max(np.abs(ref).max(), 1e-6)
+        assert out.shape == (2, ws, Tc) and out.dtype == np.float32
+
+
+@pytest.mark.parametrize('ws,hop,B,K,D', [(1024, 512, 512, 64, 64), (512, 64, 64, 256, 64), (512, 128, 256, 128, 48)])
+def test_stream_matches_oracle_with_online_localisation(ws, hop, B, K, D):
+    """Block-by-block streaming with TDOA tracking: the fused device call against OverlapAddOracle + processor oracle."""
+    from gcc_nmf_amd.realtime import StreamingGCCNMF
+    dev, ora, rng = make(ws, K, D, B // hop, seed=3, loc=True, L=6)
+    for p in (dev, ora):
+        p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    x = O.synthetic_mixture(5, numSamples=16000, delays=(-3, 1, 4))
+    n_blocks = x.shape[1] // B
+    stream = StreamingGCCNMF(dev, hop, B)
+    ola = R.OverlapAddOracle(2, ws, hop, B, B // hop)
+    tdoa_dev, tdoa_ref, worst = [], [], 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                                   # nanmean of the all-zero start-up frames
+        for b in range(n_blocks):
+            blk = x[:, b * B:(b + 1) * B]
+            yd = stream.process_block(blk)
+            yr = ola.processFrames(blk, ora.processFrames)
+            tdoa_dev.append(dev.targetTDOAIndex)
+            tdoa_ref.append(float(ora.targetTDOAIndex))
+            worst = max(worst, float(np.abs(yd - yr).max()))
+            if tdoa_dev[-1] != tdoa_ref[-1]:
+                break
+    assert tdoa_dev == tdoa_ref                                            # the tracked target, block by block
+    assert worst < 2e-4 * np.abs(x).max()
+    assert np.isfinite(yd).all()
+
+
+def test_process_stream_equals_block_calls_and_passthrough():
+    from gcc_nmf_amd.realtime import StreamingGCCNMF
+    ws, hop, B, K, D = 512, 128, 128, 64, 32
+    dev, ora, rng = make(ws, K, D, 1, seed=4, loc=False)
+    x = (rng.standard_normal((2, 40 * B)) * 0.05).astype(np.float32)
+    dev.separationEnabled = False                                          # :210-211 pass-through
+    y = StreamingGCCNMF(dev, hop, B).process_stream(x)
+    ref = R.run_stream(x, type('P', (), {'processFrames': staticmethod(lambda w: w * ora.windowFunction * ora.windowFunction)})(), ws, hop, B)
+    assert np.abs(y - ref).max() < 1e-5
+    dev.separationEnabled = True
+    dev.reset()
+    y1 = StreamingGCCNMF(dev, hop, B).process_stream(x)
+    dev.reset()
+    s2 = StreamingGCCNMF(dev, hop, B)
+    y2 = np.concatenate([s2.process_block(x[:, b * B:(b + 1) * B]) for b in range(40)], axis=1)
+    assert np.array_equal(y1, y2)
