@@ -14,6 +14,9 @@
 #include "fft_core.h"
 
 // grid = batch * ceil(T / TB); dynamic LDS = (TB*(N+ZPAD) + N/2) float2.
+// PCM16 = true: x points at interleaved int16 frames [n][2] (a wav file's data chunk); the int16 -> float32 / 32768
+// conversion of wavfile.pcm2float (gccNMF/wavfile.py:57-89) and the de-interleave ride on the load (4 bytes per lane, coalesced).
+template <bool PCM16>
 __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __restrict__ x, long x_stride, int n_samples, int N,
                                                              int logN, int hop, int T, const float* __restrict__ window,
                                                              const float2* __restrict__ twiddle, float2* __restrict__ X,
@@ -27,6 +30,7 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
     const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * FFT_TB;
     const float* xl = x + b * x_stride;
     const float* xr = xl + n_samples;
+    const short2* pcm = (const short2*)x + b * x_stride;      // PCM16: x_stride counts stereo frames
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
     for (int idx = threadIdx.x; idx < FFT_TB * N; idx += FFT_NT) {
@@ -36,7 +40,12 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
         if (t < T) {
             const float w = window[n];
             const long s = (long)t * hop + n;
-            v = make_float2(w * xl[s], w * xr[s]);
+            if (PCM16) {
+                const short2 q = pcm[s];
+                v = make_float2(w * ((float)q.x / 32768.f), w * ((float)q.y / 32768.f));
+            } else {
+                v = make_float2(w * xl[s], w * xr[s]);
+            }
         }
         z[tb * zstride + bitrev(n, logN)] = v;
     }
@@ -153,10 +162,40 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     y[sig * L + m] = acc * gain;
 }
 
+// ---- int16 egress (gccNMF/wavfile.py:39-48, :92-131) ---------------------------------------------------------
+// peak[g] = max |y| over the 2*L samples of group g (= one target of one file: what one wavwrite call sees).
+// Non-negative floats order like their bit patterns, so atomicMax on the uint image is exact and order independent.
+__global__ __launch_bounds__(256) void pcm_peak_kernel(const float* __restrict__ y, long group_len, unsigned int* __restrict__ peak) {
+    const long g = blockIdx.y;
+    const float* yg = y + g * group_len;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < group_len; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(yg[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak + g, __float_as_uint(m));
+}
+
+// y [g][2][L] float -> pcm [g][L][2] int16: clip protection (peak >= 1 -> x / peak * 0.99), x * 32768, clip, truncate.
+__global__ __launch_bounds__(256) void pcm_pack_kernel(const float* __restrict__ y, int L, const unsigned int* __restrict__ peak,
+                                                       short2* __restrict__ pcm) {
+    const long g = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= L) return;
+    const float pk = __uint_as_float(peak[g]);
+    float a = y[(g * 2) * L + m], b = y[(g * 2 + 1) * L + m];
+    if (pk >= 1.f) {
+        a = a / pk * 0.99f;
+        b = b / pk * 0.99f;
+    }
+    a = fminf(fmaxf(a * 32768.f, -32768.f), 32767.f);
+    b = fminf(fmaxf(b * 32768.f, -32768.f), 32767.f);
+    pcm[g * L + m] = make_short2((short)(int)a, (short)(int)b);
+}
+
 extern "C" {
 
-int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
-                       const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream) {
+static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch, const float* window,
+                       const float* twiddle, float* X, float* V, float* CC, bool pcm16, void* stream) {
     const int logN = ilog2_exact(n_fft);
     if (!x || !window || !twiddle || !X || logN < 6 || logN > 12 || hop < 1 || T < 1 || batch < 1) return GCCNMF_ERR_ARG;
     if ((long)(T - 1) * hop + n_fft > n_samples) return GCCNMF_ERR_ARG;
@@ -164,15 +203,29 @@ int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, 
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     const size_t lds = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
+    const void* fn = pcm16 ? (const void*)stft_stereo_kernel<true> : (const void*)stft_stereo_kernel<false>;
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)stft_stereo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GCCNMF_ERR_LAUNCH;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     }
     const int groups = gccnmf_ceil_div(T, FFT_TB);
-    hipLaunchKernelGGL(stft_stereo_kernel, dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, x, x_stride, n_samples,
-                       n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp);
+    if (pcm16)
+        hipLaunchKernelGGL(stft_stereo_kernel<true>, dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x,
+                           x_stride, n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp);
+    else
+        hipLaunchKernelGGL(stft_stereo_kernel<false>, dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x,
+                           x_stride, n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch, const float* window,
+                       const float* twiddle, float* X, float* V, float* CC, void* stream) {
+    return launch_stft(x, x_stride, n_samples, n_fft, hop, T, batch, window, twiddle, X, V, CC, false, stream);
+}
+
+int gccnmf_stft_stereo_pcm16(const short* pcm, long frame_stride, int n_samples, int n_fft, int hop, int T, int batch,
+                             const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream) {
+    return launch_stft(pcm, frame_stride, n_samples, n_fft, hop, T, batch, window, twiddle, X, V, CC, true, stream);
 }
 
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
@@ -199,6 +252,17 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
     if (L < 1) return GCCNMF_ERR_ARG;
     hipLaunchKernelGGL(istft_ola_kernel, dim3(gccnmf_ceil_div(L, 256), nsig, batch), dim3(256), 0, s, frames, n_fft, hop, T, L,
                        trim, gain, y);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scratch, short* pcm, void* stream) {
+    if (!y || !peak_scratch || !pcm || groups < 1 || L < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(peak_scratch, 0, sizeof(unsigned int) * groups, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(pcm_peak_kernel, dim3(64, groups), dim3(256), 0, s, y, 2L * L, peak_scratch);
+    GCCNMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pcm_pack_kernel, dim3(gccnmf_ceil_div(L, 256), groups), dim3(256), 0, s, y, L, peak_scratch, (short2*)pcm);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

@@ -134,13 +134,29 @@ class GCCNMFEngine(object):
             self.spec = z(B, 2 * g.S, g.Fp, g.Tp, 2)
             self.frames = z(B, 2 * g.S, T, self.n_fft)
             self.y = z(B, g.S, 2, self.L)
+            self.pcm_in = None        # set by upload_pcm16(): the STFT then reads int16 frames directly
+            self.pcm_out = None
 
     # ---- stages (each asynchronous on the current torch stream) ---------------------------------
     def stft(self):
         g = self.g
+        if self.pcm_in is not None:       # int16 interleaved frames straight from the wav data chunk
+            _hip.check(self.lib.gccnmf_stft_stereo_pcm16(_ptr(self.pcm_in), self.n_samples, self.n_samples, self.n_fft, self.hop, g.T,
+                                                         self.batch, _ptr(self.window), _ptr(self.twiddle), _ptr(self.X), _ptr(self.V),
+                                                         _ptr(self.CC), _stream()), 'gccnmf_stft_stereo_pcm16')
+            return
         _hip.check(self.lib.gccnmf_stft_stereo(_ptr(self.x), 2 * self.n_samples, self.n_samples, self.n_fft, self.hop, g.T,
                                                self.batch, _ptr(self.window), _ptr(self.twiddle), _ptr(self.X), _ptr(self.V),
                                                _ptr(self.CC), _stream()), 'gccnmf_stft_stereo')
+
+    def pack_pcm16(self):
+        """y -> int16 interleaved [batch][S][L][2] with wavwrite's clip protection per target (wavfile.py:39-48)."""
+        g = self.g
+        if self.pcm_out is None:
+            self.pcm_out = torch.zeros((self.batch, g.S, self.L, 2), dtype=torch.int16, device=self.device)
+            self.pcm_peak = torch.zeros((self.batch * g.S,), dtype=torch.int32, device=self.device)
+        _hip.check(self.lib.gccnmf_pack_pcm16(_ptr(self.y), self.batch * g.S, self.L, _ptr(self.pcm_peak), _ptr(self.pcm_out), _stream()),
+                   'gccnmf_pack_pcm16')
 
     def klnmf(self):
         g = self.g
@@ -193,7 +209,29 @@ class GCCNMFEngine(object):
             raise ValueError('expected samples of shape %s, got %s' % ((self.batch, 2, self.n_samples), x.shape))
         if not np.isfinite(x).all():
             raise ValueError('Audio buffer is not finite everywhere')      # librosaSTFT.py:488-489
+        self.pcm_in = None
         self.x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
+
+    def upload_pcm16(self, pcm):
+        """(batch, n, 2) int16 interleaved stereo frames, exactly as scipy.io.wavfile.read returns them (no host conversion)."""
+        pcm = np.asarray(pcm)
+        if pcm.ndim == 2:
+            pcm = pcm[None]
+        if pcm.dtype != np.int16 or pcm.shape != (self.batch, self.n_samples, 2):
+            raise ValueError('expected int16 frames of shape %s, got %s %s' % ((self.batch, self.n_samples, 2), pcm.dtype, pcm.shape))
+        if self.pcm_in is None:
+            self.pcm_in = torch.zeros((self.batch, self.n_samples, 2), dtype=torch.int16, device=self.device)
+        self.pcm_in.copy_(torch.from_numpy(np.ascontiguousarray(pcm)))
+
+    def separate_pcm16(self, pcm):
+        """int16 frames in -> int16 frames out: (batch, n, 2) -> (batch, S, hop*(T-1), 2), i.e. loadMixtureSignal ...
+        saveTargetSignalEstimates (runGCCNMF.py:35-54) minus the file system, with both wav conversions on the device."""
+        self.upload_pcm16(pcm)
+        self.run()
+        self.pack_pcm16()
+        out = self.pcm_out.cpu().numpy()
+        self.check_status()
+        return out
 
     def separate(self, stereoSamples):
         """(batch, 2, n) float32 host samples -> (batch, S, 2, hop*(T-1)) float32 host waveforms."""

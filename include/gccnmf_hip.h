@@ -60,6 +60,17 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
 int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
                        const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
 
+/* The same with the wav ingest fused in: pcm = interleaved int16 stereo frames [batch][n_samples][2]
+ * exactly as they sit in a wav data chunk (frame_stride stereo frames between files); the /32768 conversion of
+ * wavread -> pcm2float (gccNMF/wavfile.py:34-37, :57-89) and the de-interleave happen in the STFT's load. */
+int gccnmf_stft_stereo_pcm16(const short* pcm, long frame_stride, int n_samples, int n_fft, int hop, int T, int batch,
+                             const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
+
+/* wav egress on the device: y [groups][2][L] float32 -> pcm [groups][L][2] int16 with wavwrite's clip protection per
+ * group (peak >= 1 -> rescale to 0.99) and float2pcm's clip + truncation (gccNMF/wavfile.py:39-48, :92-131).  One group
+ * = one target of one file = one wavwrite call.  peak_scratch: `groups` uint32 of device scratch. */
+int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scratch, short* pcm, void* stream);
+
 /* KL-NMF multiplicative updates, independent dictionary per file.
  * Replaces the iteration loop of performKLNMF (gccNMFFunctions.py:75-81); the MT19937 initial
  * W, H (:70-73) are drawn on the host and passed in.  W and H are updated in place.

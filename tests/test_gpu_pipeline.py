@@ -200,3 +200,32 @@ def test_benchmark_shape_properties():
     e1 = engine(160000, dictionarySize=1024, numIterations=30, batch=1)
     y1 = e1.separate(xs[5])
     assert np.array_equal(y1[0], y[5])
+
+
+def test_pcm16_ingest_and_egress(dev1, tmp_path):
+    """int16 frames in, int16 frames out, conversions fused on the device -- against wavread / wavwrite
+    semantics (gccNMF/wavfile.py) applied to the float path, and against the reference's own waveform golden."""
+    from scipy.io import wavfile
+    from conftest import GOLDEN
+    import os
+    sr, pcm = wavfile.read(os.path.join(GOLDEN, 'data', 'dev1_female3_liverec_130ms_1m_mix.wav'))
+    assert pcm.dtype == np.int16 and pcm.shape == (160000, 2)
+    e = engine(160000, dictionarySize=128, numIterations=100)
+    out = e.separate_pcm16(pcm)[0]                                   # (3, L, 2) int16
+    assert out.dtype == np.int16 and out.shape == (3, 158976, 2)
+    y_float = e.y[0].cpu().numpy()                                    # the float waveforms of the same run
+    assert np.array_equal(out.transpose(0, 2, 1), O.float2pcm(y_float))          # egress == float2pcm, exactly (no clipping here)
+    x, _ = dev1
+    e2 = engine(160000, dictionarySize=128, numIterations=100)
+    assert np.array_equal(e2.separate(x)[0], y_float)                # ingest == pcm2float + float path, bit for bit
+    g = golden('dev1_hop256_K128')
+    assert np.abs(out.transpose(0, 2, 1).astype(int) - O.float2pcm(g['y']).astype(int)).max() <= 1   # vs the reference's output
+    # clip protection: a block whose peak exceeds 1 is rescaled to 0.99 like wavwrite
+    e.y.mul_(40.0)
+    e.pack_pcm16()
+    loud = e.pcm_out[0].cpu().numpy().transpose(0, 2, 1)
+    yl = e.y[0].cpu().numpy()
+    for i in range(3):
+        m = np.max(np.abs(yl[i]))
+        expect = O.float2pcm((yl[i] / m * 0.99).astype(np.float32)) if m >= 1 else O.float2pcm(yl[i])
+        assert np.abs(loud[i].astype(int) - expect.astype(int)).max() <= 1
