@@ -264,7 +264,7 @@ def main():
             if i < 4:
                 kern[nm]['tflops'] = flop_per_launch / (ms[i] * 1e-3) / 1e12
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_kernel<4,1,A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                            'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms)}
         if pmc and pmc.get('files_per_gpu') == B and pmc.get('dictionary_size') == K and a.seconds == 10.0 and a.hop == 256:

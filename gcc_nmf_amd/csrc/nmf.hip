@@ -10,9 +10,10 @@
 // The compensating rescale H *= norms (:81) is NOT a separate pass over H: it is the vector s,
 // applied while K1 stages its B operand and inside K2's epilogue (which rewrites H anyway).
 // gccnmf_klnmf materialises it once after the last iteration.
-#include "gemm_mfma.h"
+#include "gemm_dma.h"
 
 int gccnmf_tune_ablate = 0;
+int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 
 extern "C" {
@@ -25,6 +26,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 2 && value >= 0 && value <= 2) {
         gccnmf_tune_tile_policy = value;
+        return GCCNMF_OK;
+    }
+    if (key == 3) {
+        gccnmf_tune_dma = value ? 1 : 0;
         return GCCNMF_OK;
     }
     return GCCNMF_ERR_ARG;
@@ -206,6 +211,11 @@ static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
         if (tail) return GCCNMF_ERR_ARG;
         return gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false, 1>(a, s);
     }
+    if (tall && gccnmf_tune_dma) {
+        if (A_KC) return tail ? gccnmf_launch_gemm_dma<A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm_dma<A_KC, B_KC, EPI, false>(a, s);
+        if (tail) return GCCNMF_ERR_ARG;
+        return gccnmf_launch_gemm_dma<A_KC, B_KC, EPI, false>(a, s);
+    }
     if (A_KC) {
         if (tall) return tail ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false>(a, s);
         return tail ? gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm<1, 4, A_KC, B_KC, EPI, false>(a, s);
@@ -302,6 +312,8 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
     a.tail_row = g.F - 1;
     a.C = W; a.sC = g.sW; a.ldc = g.Kp;
     a.out_colsum = colsumW; a.out_norm = hscale; a.s_out = g.Kp;
+    if (gccnmf_tune_dma)
+        return g.tail ? gccnmf_launch_gemm_dma<true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm_dma<true, true, EPI_UPDW, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, false>(a, s);
 }
 

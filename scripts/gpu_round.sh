@@ -36,7 +36,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(files[0])):
-        if r['Counter_Name'] == c and 'gccnmf_gemm_kernel' in r['Kernel_Name']:
+        if r['Counter_Name'] == c and 'gccnmf_gemm' in r['Kernel_Name']:
             agg[r['Kernel_Name']].append(float(r['Counter_Value']))
     res[c] = {k: {'launches': len(v), 'mean_KB': sum(v) / len(v)} for k, v in agg.items()}
 json.dump(res, open(os.path.join(out, 'pmc_traffic_raw.json'), 'w'), indent=1)

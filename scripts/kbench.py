@@ -23,12 +23,14 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ablate', type=int, default=0)
+    ap.add_argument('--dma', type=int, default=1)
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
     lib.gccnmf_set_tuning(1, a.ablate)
+    lib.gccnmf_set_tuning(3, a.dma)
     F, T, K, B = 513, a.T, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N

@@ -363,3 +363,25 @@ def test_klnmf_fused_and_unfused_w_update_agree(hip, F, T, K):
     for b in range(B):
         Wr, Hr = O.performKLNMF(V[b], K, 6, 0)
         assert rel(Wf[b, :F, :K], Wr) < 1e-4 and rel(Hf[b, :K, :N], Hr) < 1e-4
+
+
+@pytest.fixture(params=[1, 0], ids=['lds-dma', 'register-staged'])
+def dma_throughput_tile(hip, request):
+    """Both operand-staging paths of the throughput tile (csrc/gemm_dma.h LDS-DMA, the default, and csrc/gemm_mfma.h
+    register staging), forced at any problem size."""
+    lib = hip.lib()
+    assert lib.gccnmf_set_tuning(2, 1) == 0 and lib.gccnmf_set_tuning(3, request.param) == 0
+    yield
+    lib.gccnmf_set_tuning(2, 0)
+    lib.gccnmf_set_tuning(3, 1)
+
+
+@pytest.mark.parametrize('F,N,K,iters,alpha', [(513, 90, 128, 12, 0), (513, 1244, 192, 5, 0.3), (257, 77, 40, 10, 0), (200, 333, 300, 5, 0),
+                                               (1025, 50, 64, 4, 0)])
+def test_klnmf_dma_staging_vs_oracle(hip, dma_throughput_tile, F, N, K, iters, alpha):
+    from gcc_nmf_amd.gccNMFFunctions import performKLNMF
+    rng = np.random.RandomState(F + N + K)
+    V = (np.abs(rng.standard_normal((F, N))) + 0.01).astype(np.float32)
+    W, H = performKLNMF(V, K, iters, alpha)
+    Wr, Hr = O.performKLNMF(V, K, iters, alpha)
+    assert rel(W, Wr) < 1e-4 and rel(H, Hr) < 1e-4, (rel(W, Wr), rel(H, Hr))

@@ -164,7 +164,9 @@ def test_benchmark_shape_properties():
       - masks partition the coefficients: sum_i S[i,c] == (W.H_c) * X_c/|X_c|
       - KL divergence D(V || W.H) after 30 iterations is below the value after 5 (multiplicative updates descend)
       - unit-L2 atoms, non-negative factors, untouched zero padding
-      - every file of the batch equals its own single-file run bit for bit."""
+      - every file of the batch equals its own single-file run: bit for bit when both runs use the same GEMM tile (the
+        result does not depend on the batch position or size), and to 1e-6 of the signal RMS under the automatic tile
+        policy (the small-batch tile sums each 16-deep k-tile in a different order than the LDS-DMA throughput tile)."""
     from gcc_nmf_amd.synthetic import synthetic_batch
     xs = synthetic_batch(100, 8)
     e = engine(160000, dictionarySize=1024, numIterations=30, batch=8)
@@ -199,6 +201,15 @@ def test_benchmark_shape_properties():
 
     e1 = engine(160000, dictionarySize=1024, numIterations=30, batch=1)
     y1 = e1.separate(xs[5])
+    assert e1.get_tdoa_indexes().tolist() == [[27, 59, 91]]
+    assert np.sqrt(np.mean((y1[0] - y[5]) ** 2)) < 1e-6 * np.sqrt(np.mean(y[5] ** 2))
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    assert lib.gccnmf_set_tuning(2, 1) == 0
+    try:
+        y1 = e1.separate(xs[5])
+    finally:
+        lib.gccnmf_set_tuning(2, 0)
     assert np.array_equal(y1[0], y[5])
 
 
