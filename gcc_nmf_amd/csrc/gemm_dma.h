@@ -44,46 +44,78 @@ __device__ __forceinline__ gemm_f32x2 gemm_lds_read2_b32(unsigned byte_addr) {
     return v;
 }
 
-// all fragments of one k half (q) of a tile; every address is ONE per-operand base VGPR + an immediate offset
-template <bool A_KC, bool B_KC, int BM, int BN, int TM>
-__device__ __forceinline__ void gemm_dma_read_frags(gemm_f32x4 (&av)[TM], gemm_f32x4 (&bv)[2], unsigned baseA, unsigned baseB) {
-    // KC:     base = lds + 4*(row0*16 + 4*(chunk ^ swz(row0))); rows row0 + 32*m share swz -> offset m*2048
-    // non-KC: base = lds + 4*(4*chunk*B + row0);                element e of row m at offset 4*(e*B + 32*m)
-    if (A_KC) {
-        av[0] = gemm_lds_read_b128<0 * 2048>(baseA);
-        av[1] = gemm_lds_read_b128<1 * 2048>(baseA);
-        av[2] = gemm_lds_read_b128<2 * 2048>(baseA);
-        av[3] = gemm_lds_read_b128<3 * 2048>(baseA);
-    } else {
-        // element e of rows m, m+1 are 32 dwords apart: one ds_read2_b32 each; the e stride (BM dwords) goes into the base
-#define GEMM_RD_A(e_, f_)                                                                        \
-    {                                                                                            \
-        const gemm_f32x2 lo = gemm_lds_read2_b32<0, 32>(baseA + 4 * (e_) * BM);                  \
-        const gemm_f32x2 hi = gemm_lds_read2_b32<64, 96>(baseA + 4 * (e_) * BM);                 \
-        av[0].f_ = lo.x; av[1].f_ = lo.y; av[2].f_ = hi.x; av[3].f_ = hi.y;                      \
-    }
-        GEMM_RD_A(0, x) GEMM_RD_A(1, y) GEMM_RD_A(2, z) GEMM_RD_A(3, w)
-#undef GEMM_RD_A
-    }
-    if (B_KC) {
-        bv[0] = gemm_lds_read_b128<0>(baseB);
-        bv[1] = gemm_lds_read_b128<2048>(baseB);
-    } else {
-#define GEMM_RD_B(e_, f_)                                                                        \
-    {                                                                                            \
-        const gemm_f32x2 v2 = gemm_lds_read2_b32<0, 32>(baseB + 4 * (e_) * BN);                  \
-        bv[0].f_ = v2.x; bv[1].f_ = v2.y;                                                        \
-    }
-        GEMM_RD_B(0, x) GEMM_RD_B(1, y) GEMM_RD_B(2, z) GEMM_RD_B(3, w)
-#undef GEMM_RD_B
-    }
+template <int OFF>
+__device__ __forceinline__ float gemm_lds_read_b32(unsigned byte_addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
 }
+// "The LDS reads issued so far have landed": an s_waitcnt followed by empty asm statements that take the destination
+// registers as in/out operands (asm volatile statements keep their order), so the compiler can neither hoist a use above
+// the wait nor copy a register before its data has arrived.  Nothing may touch a destination between the read and its tie.
+__device__ __forceinline__ void gemm_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ void gemm_tie(T& v) { asm volatile("" : "+v"(v)); }
+
+// MFMA fragments of one k half (4 consecutive MFMA steps e = 0..3) for NT 32-row tiles; every address is ONE base VGPR +
+// an immediate offset.
+template <bool KC, int NT, int ROWS>
+struct GemmFrag;
+// reduction-contiguous operand: base = buffer + 4*(row0*16 + 4*(chunk ^ swz(row0))); rows row0 + 32*m share swz -> offset m*2048
+template <int NT, int ROWS>
+struct GemmFrag<true, NT, ROWS> {
+    gemm_f32x4 v[NT];
+    __device__ __forceinline__ void read(unsigned base) {
+        v[0] = gemm_lds_read_b128<0 * 2048>(base);
+        v[1] = gemm_lds_read_b128<1 * 2048>(base);
+        if (NT == 4) {
+            v[2] = gemm_lds_read_b128<2 * 2048>(base);
+            v[3] = gemm_lds_read_b128<3 * 2048>(base);
+        }
+    }
+    __device__ __forceinline__ void tie() {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) gemm_tie(v[m]);
+    }
+    __device__ __forceinline__ float get(int m, int e) const { return v[m][e]; }
+    __device__ __forceinline__ void scale(const gemm_f32x4& s) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) v[m] *= s;
+    }
+};
+// reduction-strided operand [k][ROWS]: base = buffer + 4*(4*chunk*ROWS + row0); element e of tile m at 4*(e*ROWS + 32*m):
+// tiles m, m+1 come from one ds_read2_b32, the e stride goes into the base
+template <int NT, int ROWS>
+struct GemmFrag<false, NT, ROWS> {
+    gemm_f32x2 v[4][NT / 2];
+    __device__ __forceinline__ void read(unsigned base) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e][0] = gemm_lds_read2_b32<0, 32>(base + 4 * e * ROWS);
+            if (NT == 4) v[e][1] = gemm_lds_read2_b32<64, 96>(base + 4 * e * ROWS);
+        }
+    }
+    __device__ __forceinline__ void tie() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < NT / 2; ++h) gemm_tie(v[e][h]);
+    }
+    __device__ __forceinline__ float get(int m, int e) const { return v[e][m >> 1][m & 1]; }
+    __device__ __forceinline__ void scale(const gemm_f32x4& s) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < NT / 2; ++h) v[e][h] *= s[e];
+    }
+};
 
 template <bool A_KC, bool B_KC, int EPI, bool TAIL>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     constexpr int BK = 16, TM = 4, BM = 512, BN = 64;
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
+    constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);   // K1 (R = V / (W.(s*H))) carries a lazy row scale on its B operand
     __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
 
     const int tiles = p.tiles_m * p.tiles_n;
@@ -101,13 +133,36 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const int row0 = tm * BM, col0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
+
+    // Phase offset between the two workgroups that share a CU.  All workgroups of a launch are equally long, so without it
+    // every CU runs main loop | main loop and then epilogue | epilogue: the whole chip bursts its V/H/R epilogue traffic
+    // into HBM at the same moments while every matrix pipe idles.  The SECOND workgroup to arrive on a CU in this launch
+    // (found by stamping a per-CU slot, keyed by the hardware CU id -- speed only, nothing depends on placement) sleeps
+    // for a fraction of a main loop; the first one meanwhile has the matrix pipe to itself (2x rate), nothing is lost,
+    // and from then on one workgroup's epilogue overlaps the other's MFMAs.  Later arrivals start immediately.
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+    if (p.stagger_loops > 0) {
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);           // HW_REG_HW_ID: cu_id/sh_id/se_id in [15:8]
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);          // HW_REG_XCC_ID[3:0]
+            const int cu = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
+            if (atomicExch(&p.cu_table[cu], p.epoch) == p.epoch && atomicExch(&p.cu_table[4096 + cu], p.epoch) != p.epoch) {
+                for (int i = 0; i < p.stagger_loops; ++i) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        __syncthreads();
+    }
+    if (p.trace && tid == 0) {
+        p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    }
     const int wm = wave, wn = 0;
     const int l31 = lane & 31, hh = lane >> 5;
     const int arow = wm * 128 + l31, bcol = wn * 64 + l31;
 
     const float* __restrict__ A = p.A + file * p.sA;
     const float* __restrict__ B = p.B + file * p.sB;
-    const float* __restrict__ bscale = (!B_KC && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
+    const float* __restrict__ bscale = (SCALE && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
     const bool wave_active = (row0 + wm * 128) < p.M;
     const bool do_tail = TAIL && (tm == 0);
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
@@ -142,109 +197,210 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
-#define GEMM_DMA_TILE(kt_, buf_)                                                                               \
-    do {                                                                                                       \
-        float* sb_ = smem + (buf_) * SBUF;                                                                     \
-        const float* At_ = A + (A_KC ? (long)(kt_) * BK : (long)(kt_) * BK * p.lda);                           \
-        const float* Bt_ = B + (B_KC ? (long)(kt_) * BK : (long)(kt_) * BK * p.ldb);                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) gemm_dma16(At_ + offA[i_], sb_ + (wave * 8 + i_) * 256); \
-        gemm_dma16(Bt_ + offB, sb_ + SA + wave * 256);                                                         \
-        if (TAIL) {                                                                                            \
-            if (do_tail && wave == 0 && lane < 4) gemm_dma16(A + (long)p.tail_row * p.lda + (kt_) * BK + 4 * lane, sb_ + SA + SB); \
-        }                                                                                                      \
-        if (!B_KC) {                                                                                           \
-            if (bscale && wave == 1 && lane < 4) gemm_dma16(bscale + (kt_) * BK + 4 * lane, sb_ + SA + SB + BK); \
-        }                                                                                                      \
-    } while (0)
-
     const int nkt = (p.Kd + BK - 1) / BK;
-    GEMM_DMA_TILE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const float* __restrict__ tailA = A + (long)p.tail_row * p.lda + 4 * (lane & 3);
+    const bool tail_dma = TAIL && do_tail && wave == 0 && lane < 4, scale_dma = SCALE && bscale && wave == 1 && lane < 4;
 
-    // One k-tile.  CUR (which staging buffer holds the tile) is a COMPILE-TIME constant: with a run-time buffer index the
-    // compiler cannot prove that the LDS-DMA destination (the other buffer) does not alias this step's ds_reads and
-    // drains the DMA queue (s_waitcnt vmcnt(0)) before the first fragment read, serialising copy and compute.
-    auto step = [&](auto cur_c, const int kt) {
-        constexpr int CUR = decltype(cur_c)::value;
-        const float* __restrict__ sA = smem + CUR * SBUF;
-        const float* __restrict__ sB = sA + SA;
-        const float* __restrict__ sT = sB + SB;
-        const float* __restrict__ sS = sT + BK;
+    // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
+    // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop, one piece per two MFMAs.)
+    auto dma_piece = [&](const int piece, const int kt, const int buf) {
+        float* sb = smem + buf * SBUF;
+        if (piece < 8) {
+            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda) + offA[piece], sb + (wave * 8 + piece) * 256);
+        } else if (piece == 8) {
+            gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb) + offB, sb + SA + wave * 256);
+        } else {
+            if (TAIL) {
+                if (tail_dma) gemm_dma16(tailA + kt * BK, sb + SA + SB);
+            }
+            if (SCALE) {
+                if (scale_dma) gemm_dma16(bscale + kt * BK + 4 * lane, sb + SA + SB + BK);
+            }
+        }
+    };
+    constexpr int NPIECES = 10;
+    // how the pieces are dealt out over the 16 MFMA pairs of group 0 -- 0: all before the first MFMA; 1: one per pair;
+    // 2: two per three pairs.  Measured (64 files, K = 1024): W.H (A reduction-contiguous, B not) 0.816 / 0.698 / 0.699 ms,
+    // R.H^T (both reduction-contiguous: every piece is 16 rows x 64 B) 0.777 / 0.779 / 0.750 ms, W^T.R 0.829 / 0.829 / 0.818 ms.
+#ifdef GEMM_DMA_SPREAD
+    constexpr int SPREAD = GEMM_DMA_SPREAD;
+#else
+    constexpr int SPREAD = (A_KC && !B_KC) ? 1 : 2;
+#endif
 
-        // hipcc drains the LDS-DMA queue (s_waitcnt vmcnt(0)) in front of ANY compiler-visible ds_read that follows a
-        // global_load_lds, which would serialise copy and compute.  So: the few reads the compiler sees (tail row, row
-        // sums, row scale) go first, and the MFMA fragments are read with inline-asm ds_read (waits counted by hand).
-        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f), tb4 = t4, rs4 = t4, sc4[2] = {t4, t4};
+    // Fragment registers.  Group 0 = first k half (q = 0) of a tile + its row-scale chunk; group 1 = second half + the
+    // operands of the VALU side work (tail row, row sums).  All LDS reads are inline asm (the compiler would drain the
+    // LDS-DMA queue, s_waitcnt vmcnt(0), in front of any ds_read it can see after a global_load_lds); every group is
+    // made visible by gemm_wait_*(): an `s_waitcnt lgkmcnt(0)` that "redefines" the registers, so no use can move above it.
+    const gemm_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    GemmFrag<A_KC, TM, BM> a0, a1;
+    GemmFrag<B_KC, 2, BN> b0, b1;
+    gemm_f32x4 sc0 = zero4, sc1 = zero4, t4 = zero4, tb4 = zero4, ts4 = zero4, rs4 = zero4;
+    float tbx = 0.f, tby = 0.f, tbz = 0.f, tbw = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)(gemm_lds_ptr)smem;
+    // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
+    const unsigned oA0 = A_KC ? 4 * (arow * 16 + 4 * ((0 + hh) ^ gemm_swz(arow))) : 4 * (4 * (0 + hh) * BM + arow);
+    const unsigned oA1 = A_KC ? 4 * (arow * 16 + 4 * ((2 + hh) ^ gemm_swz(arow))) : 4 * (4 * (2 + hh) * BM + arow);
+    const unsigned oB0 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((0 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (0 + hh) * BN + bcol));
+    const unsigned oB1 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((2 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (2 + hh) * BN + bcol));
+    const int tj = tid & 63, tg = tid >> 6;                        // tail row: 4 thread groups x 4 reduction steps each
+    const unsigned oTB = 4 * SA + (B_KC ? 4 * (tj * 16 + 4 * (tg ^ gemm_swz(tj))) : 4 * (4 * tg * BN + tj));
+    const unsigned oRS = 4 * SA + 4 * ((tid >> 2) * 16 + 4 * (tid & 3));   // row sums: 4 threads per atom row, one chunk each
+
+    auto read_group0 = [&](const unsigned lds) {                    // lds = byte address of the staging buffer
+        if (wave_active) {
+            a0.read(lds + oA0);
+            b0.read(lds + oB0);
+        }
+        if (SCALE) sc0 = gemm_lds_read_b128<4 * (SA + SB + BK)>(lds + 16 * hh);
+    };
+    auto read_group1 = [&](const unsigned lds) {
+        if (wave_active) {
+            a1.read(lds + oA1);
+            b1.read(lds + oB1);
+        }
+        if (SCALE) sc1 = gemm_lds_read_b128<4 * (SA + SB + BK) + 32>(lds + 16 * hh);
         if (TAIL) {
             if (do_tail) {
-                const int j = tid & 63, g = tid >> 6;                  // 4 thread groups x 4 reduction steps
-                t4 = *(const float4*)(sT + 4 * g);
+                t4 = gemm_lds_read_b128<4 * (SA + SB)>(lds + 16 * tg);
                 if (B_KC) {
-                    tb4 = *(const float4*)(sB + j * 16 + 4 * (g ^ gemm_swz(j)));
+                    tb4 = gemm_lds_read_b128<0>(lds + oTB);
                 } else {
-                    tb4.x = sB[(4 * g + 0) * BN + j];
-                    tb4.y = sB[(4 * g + 1) * BN + j];
-                    tb4.z = sB[(4 * g + 2) * BN + j];
-                    tb4.w = sB[(4 * g + 3) * BN + j];
-                    if (bscale) {
-                        const float4 s4 = *(const float4*)(sS + 4 * g);
-                        tb4.x *= s4.x;
-                        tb4.y *= s4.y;
-                        tb4.z *= s4.z;
-                        tb4.w *= s4.w;
-                    }
+                    tbx = gemm_lds_read_b32<0 * 4 * BN>(lds + oTB);
+                    tby = gemm_lds_read_b32<1 * 4 * BN>(lds + oTB);
+                    tbz = gemm_lds_read_b32<2 * 4 * BN>(lds + oTB);
+                    tbw = gemm_lds_read_b32<3 * 4 * BN>(lds + oTB);
+                    if (SCALE) ts4 = gemm_lds_read_b128<4 * (SA + SB + BK)>(lds + 16 * tg);
                 }
             }
         }
         if (B_KC) {
-            if (do_rowsum) rs4 = *(const float4*)(sB + (tid >> 2) * 16 + 4 * (tid & 3));   // 4 threads per atom row, one chunk each
-        } else if (bscale) {
-            sc4[0] = *(const float4*)(sS + 4 * hh);
-            sc4[1] = *(const float4*)(sS + 4 * (2 + hh));
+            if (do_rowsum) rs4 = gemm_lds_read_b128<0>(lds + oRS);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-
-        const unsigned ldsA = (unsigned)(size_t)(gemm_lds_ptr)(smem + CUR * SBUF), ldsB = ldsA + 4 * SA;
-        gemm_f32x4 av[2][TM], bv[2][2];
-        auto read_frags = [&](const int q) {
-            const int cq = 2 * q + hh;                                 // this lane half's 16-byte k chunk
-            const unsigned bA = A_KC ? ldsA + 4 * (arow * 16 + 4 * (cq ^ gemm_swz(arow))) : ldsA + 4 * (4 * cq * BM + arow);
-            const unsigned bB = B_KC ? ldsB + 4 * (bcol * 16 + 4 * (cq ^ gemm_swz(bcol))) : ldsB + 4 * (4 * cq * BN + bcol);
-            gemm_dma_read_frags<A_KC, B_KC, BM, BN, TM>(av[q], bv[q], bA, bB);
-        };
-        auto mma32 = [&](const int q) {
-            if (!B_KC) {
-                if (bscale) {                                          // lazy H row scale: fl(H * s), as the staged form did
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        bv[q][n].x *= sc4[q].x;
-                        bv[q][n].y *= sc4[q].y;
-                        bv[q][n].z *= sc4[q].z;
-                        bv[q][n].w *= sc4[q].w;
-                    }
+    };
+    auto wait_group0 = [&]() {
+        gemm_wait_lds();
+        a0.tie();
+        b0.tie();
+        if (SCALE) {
+            gemm_tie(sc0);
+            if (bscale) b0.scale(sc0);                             // lazy H row scale: fl(H * s), as the staged form does
+        }
+    };
+    auto wait_group1 = [&]() {
+        gemm_wait_lds();
+        a1.tie();
+        b1.tie();
+        if (SCALE) {
+            gemm_tie(sc1);
+            if (bscale) b1.scale(sc1);
+        }
+        if (TAIL) {
+            gemm_tie(t4);
+            if (B_KC) {
+                gemm_tie(tb4);
+            } else {
+                gemm_tie(tbx);
+                gemm_tie(tby);
+                gemm_tie(tbz);
+                gemm_tie(tbw);
+                tb4 = gemm_f32x4{tbx, tby, tbz, tbw};
+                if (SCALE) {
+                    gemm_tie(ts4);
+                    if (bscale) tb4 *= ts4;
                 }
+            }
+        }
+        if (B_KC) gemm_tie(rs4);
+    };
+    auto mma = [&](const GemmFrag<A_KC, TM, BM>& a, const GemmFrag<B_KC, 2, BN>& b, const int e, const int m) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(0, e), acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(1, e), acc[m][1], 0, 0, 0);
+    };
+
+    // prologue: tile 0 -> buffer 0, group 0 of tile 0 into registers
+#pragma unroll
+    for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_group0(lds0);
+    wait_group0();
+
+    // One k-tile, software-pipelined ACROSS the workgroup barrier so that no wave has an MFMA-free stretch per tile (two
+    // co-resident workgroups fall into lock-step -- the one behind gets the whole matrix pipe whenever the leader is busy
+    // with something else and catches up -- so any such stretch is matrix-pipe idle time on the whole SIMD):
+    //     issue reads of group 1 (tile t)                         | buffer CUR
+    //     32 MFMAs of group 0, the 10 LDS-DMA pieces of tile t+1 dealt out one per two MFMAs   | -> buffer CUR^1
+    //     wait group 1;  first 16 MFMAs of group 1
+    //     wait LDS-DMA;  barrier  (tile t+1 visible; every wave is past its last LDS read of tile t)
+    //     issue reads of group 0 (tile t+1)                       | buffer CUR^1
+    //     last 16 MFMAs of group 1, tail-row / row-sum FMAs;  wait group 0
+    // CUR is a compile-time constant so that all LDS offsets are immediates.  The piece loads of the step after the last
+    // re-fetch the last tile (valid addresses, never read): cheaper than a branch around every piece.
+#ifdef GEMM_DMA_PROBE
+    // build-time instrumentation (make variant X=-DGEMM_DMA_PROBE, scripts/ktrace.py --probe): shader-clock cycles per
+    // phase of the k-tile, summed over the main loop, per wave
+    unsigned long long probe[7] = {0, 0, 0, 0, 0, 0, 0};
+#define GEMM_PROBE(i_) const unsigned long long pt##i_ = __builtin_amdgcn_s_memtime()
+#else
+#define GEMM_PROBE(i_)
+#endif
+    auto step = [&](auto cur_c, const int kt) {
+        constexpr int CUR = decltype(cur_c)::value;
+        const unsigned ldsC = lds0 + 4 * CUR * SBUF, ldsN = lds0 + 4 * (CUR ^ 1) * SBUF;
+        const int ktn = min(kt + 1, nkt - 1);
+        GEMM_PROBE(0);
+        read_group1(ldsC);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave_active) {
+            if (SPREAD == 0) {
+#pragma unroll
+                for (int i = 0; i < NPIECES; ++i) dma_piece(i, ktn, CUR ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int m = 0; m < TM; ++m)
+                for (int m = 0; m < TM; ++m) {
+                    mma(a0, b0, e, m);
+                    const int slot = e * TM + m;
+                    if (SPREAD == 1 && slot < NPIECES) {
+                        dma_piece(slot, ktn, CUR ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (SPREAD == 2 && slot % 3 != 2 && (slot / 3) * 2 + slot % 3 < NPIECES) {
+                        dma_piece((slot / 3) * 2 + slot % 3, ktn, CUR ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        } else {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m][e], bv[q][n][e], acc[m][n], 0, 0, 0);
-        };
-        if (wave_active) read_frags(0);
-        // tile kt+1 streams into the other buffer (last read in step kt-1, which every wave has left)
-        if (kt + 1 < nkt && !(p.ablate & 1)) GEMM_DMA_TILE(kt + 1, CUR ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < NPIECES; ++i) dma_piece(i, ktn, CUR ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_PROBE(1);
+        wait_group1();
+        GEMM_PROBE(2);
+        if (wave_active) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int m = 0; m < TM; ++m) mma(a1, b1, e, m);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_PROBE(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_PROBE(4);
+        __syncthreads();
+        GEMM_PROBE(5);
+        read_group0(ldsN);
         __builtin_amdgcn_sched_barrier(0);
         if (wave_active) {
-            read_frags(1);                                             // in flight under the 32 MFMAs of the first half
-            __builtin_amdgcn_sched_barrier(0);
-            mma32(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma32(1);
+#pragma unroll
+            for (int e = 2; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < TM; ++m) mma(a1, b1, e, m);
         }
         if (TAIL) {
             if (do_tail) {
@@ -257,17 +413,42 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         if (B_KC) {
             if (do_rowsum) rowsum_acc += (rs4.x + rs4.y) + (rs4.z + rs4.w);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(p.ablate & 4)) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_PROBE(6);
+        wait_group0();
+#ifdef GEMM_DMA_PROBE
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long pt7 = __builtin_amdgcn_s_memtime();
+        probe[0] += pt1 - pt0;      // group-1 read issue, 32 MFMAs, LDS-DMA pieces
+        probe[1] += pt2 - pt1;      // wait group 1
+        probe[2] += pt3 - pt2;      // 16 MFMAs
+        probe[3] += pt4 - pt3;      // wait LDS-DMA
+        probe[4] += pt5 - pt4;      // barrier
+        probe[5] += pt6 - pt5;      // group-0 read issue, 16 MFMAs, side FMAs
+        probe[6] += pt7 - pt6;      // wait group 0
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         step(std::integral_constant<int, 0>{}, kt);
         if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
     }
-#undef GEMM_DMA_TILE
+    __syncthreads();                      // the epilogues reuse the staging buffers
+#ifdef GEMM_DMA_PROBE
+    if (p.trace && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) p.trace[8 * ((long)gridDim.x + blockIdx.x * 4 + wave) + i] = (long long)probe[i];
+    }
+#endif
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 
     if (EPI == EPI_UPDW) {
         gemm_epilogue_update_w<TAIL>(p, file, col0, tid, wm, l31, hh, acc, tail_acc, rowsum_acc, smem);
+        if (p.trace) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        }
         return;
     }
     if (wave_active) {
@@ -295,6 +476,11 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             if ((tid & 3) == 0 && (col0 + j) < p.N) p.rowsumB[file * p.s_rowsumB + col0 + j] = s;
         }
     }
+    if (p.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <bool A_KC, bool B_KC, int EPI, bool TAIL>
@@ -312,6 +498,22 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     } else {
         a.xcd_affine = 0;
         grid = a.batch * tiles;
+    }
+    a.trace = (gccnmf_trace_buf && 5 * grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;   // timeline + 4 per-wave probe rows
+    // phase offset of co-resident workgroups: only worth it when every CU gets at least two workgroups, and measured to
+    // pay only for the fused W update, whose epilogue is the longest (R.H^T 0.788 -> 0.748 ms at 40 %; W.H, W^T.R unchanged)
+    a.stagger_loops = 0;
+    a.cu_table = nullptr;
+    if (gccnmf_tune_stagger > 0 && grid >= 512 && EPI == EPI_UPDW) {
+        static int* table = nullptr;
+        static int epoch = 0;
+        if (!table) {
+            if (hipMalloc(&table, 2 * 4096 * sizeof(int)) != hipSuccess || hipMemset(table, 0, 2 * 4096 * sizeof(int)) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        }
+        a.cu_table = table;
+        a.epoch = ++epoch;
+        const int nkt = gccnmf_ceil_div(a.Kd, 16);
+        a.stagger_loops = (int)((long)nkt * 8192 * gccnmf_tune_stagger / 100 / (127 * 64));     // shared-pipe main loop = 8192 cycles per k-tile
     }
     hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL>), dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();

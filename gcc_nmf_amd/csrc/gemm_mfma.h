@@ -41,6 +41,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // run-time tuning knobs (gccnmf_set_tuning); defined in nmf.hip
 extern int gccnmf_tune_ablate;
+extern long long* gccnmf_trace_buf;
+extern int gccnmf_trace_blocks;
+extern int gccnmf_tune_stagger;    // percent of one workgroup's main loop by which the 2nd workgroup on a CU starts late (gemm_dma.h)
 
 enum GemmEpilogue {
     EPI_STORE = 0,   // C[row][col] = acc
@@ -83,6 +86,9 @@ struct GemmArgs {
     long sX;
     float alpha, eps;
     int T, Tp, Fp, ldv;        // EPI_PHASE geometry
+    int* cu_table;             // gemm_dma.h phase offset: per-CU arrival stamps, launch stamp, s_sleep(127) rounds for the 2nd arrival
+    int epoch, stagger_loops;
+    long long* trace;          // debug: per-workgroup timeline, 8 x int64 per block (gccnmf_debug_set_trace)
 };
 
 template <int EPI>
@@ -178,8 +184,13 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
         for (int r = 0; r < 16; ++r) {
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             if (row < p.M) {
+#ifdef GEMM_FAST_DIV
+                if (ok_a) C[(long)row * p.ldc + col_a] = va[r] * __builtin_amdgcn_rcpf(acc_a[r]);
+                if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] * __builtin_amdgcn_rcpf(acc_b[r]);
+#else
                 if (ok_a) C[(long)row * p.ldc + col_a] = va[r] / acc_a[r];
                 if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] / acc_b[r];
+#endif
             }
         }
     } else if (EPI == EPI_UPDH) {
@@ -201,8 +212,14 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             const float d = den[r] + p.alpha + p.eps;
             if (row < p.M) {
+#ifdef GEMM_FAST_DIV
+                const float rd = __builtin_amdgcn_rcpf(d);
+                if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] * rd);
+                if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] * rd);
+#else
                 if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] / d);
                 if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] / d);
+#endif
             }
         }
     } else {  // EPI_PHASE: one tile at a time (X is two registers per element)

@@ -15,6 +15,9 @@
 int gccnmf_tune_ablate = 0;
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
+long long* gccnmf_trace_buf = nullptr;
+int gccnmf_trace_blocks = 0;
+int gccnmf_tune_stagger = 40;      // start offset of the 2nd workgroup on a CU, percent of one main loop (gemm_dma.h)
 
 extern "C" {
 int gccnmf_version(void) { return 101; }
@@ -32,7 +35,17 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_dma = value ? 1 : 0;
         return GCCNMF_OK;
     }
+    if (key == 4 && value >= 0 && value <= 100) {
+        gccnmf_tune_stagger = value;
+        return GCCNMF_OK;
+    }
     return GCCNMF_ERR_ARG;
+}
+
+int gccnmf_debug_set_trace(long long* buf, int blocks) {
+    gccnmf_trace_buf = buf;
+    gccnmf_trace_blocks = buf ? blocks : 0;
+    return GCCNMF_OK;
 }
 
 int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
@@ -488,6 +501,14 @@ int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, in
     a.C = C; a.sC = sC; a.ldc = ldc;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = layout & 8;
+    if (!wide && gccnmf_tune_dma) {       // the throughput tile's default staging path (tuning key 3)
+        switch (layout & 3) {
+            case 0: return tail ? GCCNMF_ERR_ARG : gccnmf_launch_gemm_dma<false, false, EPI_STORE, false>(a, s);
+            case 1: return tail ? gccnmf_launch_gemm_dma<true, false, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_dma<true, false, EPI_STORE, false>(a, s);
+            case 3: return tail ? gccnmf_launch_gemm_dma<true, true, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_dma<true, true, EPI_STORE, false>(a, s);
+            default: return GCCNMF_ERR_UNSUPPORTED;
+        }
+    }
     switch (layout & 3) {
         case 0:
             if (tail) return GCCNMF_ERR_ARG;

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ablate', type=int, default=0)
     ap.add_argument('--dma', type=int, default=1)
+    ap.add_argument('--stagger', type=int, default=-1)
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
@@ -31,6 +32,8 @@ def main():
     lib = _hip.lib()
     lib.gccnmf_set_tuning(1, a.ablate)
     lib.gccnmf_set_tuning(3, a.dma)
+    if a.stagger >= 0:
+        lib.gccnmf_set_tuning(4, a.stagger)
     F, T, K, B = 513, a.T, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N
@@ -63,6 +66,8 @@ def main():
         'K1 shape, store only (A_KC, tail)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Fp * g.Np),
         'K2 shape, store only (W^T.R)': lambda: dbg(W, R, G2, K, N, F, g.Kp, g.Np, g.Np, g.Kp - 4, g.Np - 4, 0, g.Fp * g.Kp, g.Fp * g.Np, g.Kp * g.Np),
         'K4a shape, store only (KC,KC, tail)': lambda: dbg(R, H, U, F, K, N, g.Np, g.Np, g.Kp, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Kp),
+        'K1 shape, store only, ONE H for all files (B L2-resident)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, 0, g.Fp * g.Np),
+        'K1 shape, store only, ONE W,H, one output tile set': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, 0, 0, 0),
         'K1 shape -> other output buffer': lambda: dbg(W, H, G2, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
         'K1 shape, N=1280 (full last tile)': lambda: dbg(W, H, G2, F, g.Np, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
         'K1 shape, no tail row (M=512)': lambda: dbg(W, H, G2, 512, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Per-workgroup timeline of one KL-NMF GEMM launch at the headline shape (gccnmf_debug_set_trace): when each workgroup
+started, left its main loop and finished its epilogue, and on which CU.
+
+    python scripts/ktrace.py [--stage 1] [--stagger 0] [--files 64] > gpurun_out/trace.json
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--files', type=int, default=64)
+    ap.add_argument('--K', type=int, default=1024)
+    ap.add_argument('--stage', type=int, default=1)
+    ap.add_argument('--stagger', type=int, default=0)
+    ap.add_argument('--dump', default='')
+    ap.add_argument('--probe', action='store_true', help='library built with -DGEMM_DMA_PROBE: per-phase cycles of the k-tile')
+    a = ap.parse_args()
+    import torch
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.engine import Geometry, _ptr, _stream
+    lib = _hip.lib()
+    lib.gccnmf_set_tuning(4, a.stagger)
+    F, T, K, B = 513, 622, a.K, a.files
+    g = Geometry(F, T, K)
+    N = g.N
+    dev = 'cuda'
+    gen = torch.Generator(device=dev).manual_seed(0)
+    V = torch.zeros((B, g.Fp, g.Np), device=dev)
+    W = torch.zeros((B, g.Fp, g.Kp), device=dev)
+    H = torch.zeros((B, g.Kp, g.Np), device=dev)
+    V[:, :F, :N] = torch.rand((B, F, N), device=dev, generator=gen) + 0.01
+    W[:, :F, :K] = torch.rand((B, F, K), device=dev, generator=gen) + 0.01
+    H[:, :K, :N] = torch.rand((B, K, N), device=dev, generator=gen) + 0.01
+    ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), device=dev)
+
+    def stage(s):
+        _hip.check(lib.gccnmf_klnmf_stage(_ptr(V), _ptr(W), _ptr(H), _ptr(ws), F, N, K, B, 0.0, 1e-16, 0, s, _stream()), 'stage')
+
+    for s in (1, 2, 3, 4):
+        stage(s)
+    torch.cuda.synchronize()
+    nblk = 16384
+    trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+    lib.gccnmf_debug_set_trace(_ptr(trace), nblk)
+    stage(a.stage)
+    torch.cuda.synchronize()
+    lib.gccnmf_debug_set_trace(None, 0)
+    t_all = trace.cpu().numpy()
+    tiles = {1: 1 * (g.Np // 64), 3: 1 * (g.Np // 64), 2: -(-K // 512) * (g.Np // 64), 4: -(-K // 64)}[a.stage]
+    grid = 8 * (-(-B // 8)) * tiles
+    t = t_all[:grid]
+    if a.probe:
+        pr = t_all[grid:5 * grid, :7].reshape(grid, 4, 7).astype(np.float64)
+        nkt = {1: K // 16, 3: K // 16, 2: (F - 1) // 16, 4: g.Np // 16}[a.stage]
+        names = ['G1 issue + 32 MFMA + DMA', 'wait G1', '16 MFMA', 'wait DMA', 'barrier', 'G0 issue + 16 MFMA', 'wait G0']
+        start = (t[:, 0] - t[:, 0].min()) / 100.0
+        loop = (t[:, 2] - t[:, 1]) / 100.0
+        first = start < 5
+        groups = {'round 1, faster half (older on its CU)': first & (loop <= np.median(loop[first])),
+                  'round 1, slower half (younger)': first & (loop > np.median(loop[first])),
+                  'last round (alone on its CU most of the time)': start > np.percentile(start, 85)}
+        for name, sel in groups.items():
+            m = pr[sel].mean(axis=(0, 1)) / nkt
+            print('%s: %d workgroups, main loop %.0f us, cycles per k-tile %.0f (solo MFMA time 4096)' % (name, sel.sum(), loop[sel].mean(), m.sum()))
+            for n, v in zip(names, m):
+                print('     %-28s %7.0f' % (n, v))
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    us = (t[:, :4] - t0) / 100.0                     # 100 MHz -> microseconds
+    cu = t[:, 4]
+    order = np.argsort(us[:, 0])
+    print('stage %d, stagger %d: %d workgroups on %d distinct CUs, launch span %.1f us' % (a.stage, a.stagger, len(t), len(np.unique(cu >> 8)), us[:, 3].max()))
+    print('  start offset wait  (t1-t0): median %.1f  p90 %.1f  max %.1f us' % tuple(np.percentile(us[:, 1] - us[:, 0], [50, 90, 100])))
+    print('  main loop          (t2-t1): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 2] - us[:, 1], [50, 10, 90])))
+    print('  epilogue           (t3-t2): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 3] - us[:, 2], [50, 10, 90])))
+    # how many workgroups are in their epilogue / main loop over time
+    edges = np.arange(0, us[:, 3].max() + 10, 10.0)
+    in_epi = [(np.sum((us[:, 2] <= x) & (us[:, 3] > x)), np.sum((us[:, 1] <= x) & (us[:, 2] > x))) for x in edges]
+    print('  t[us]: workgroups in epilogue / in main loop')
+    print('   ' + '  '.join('%.0f:%d/%d' % (x, e, m) for x, (e, m) in zip(edges, in_epi)))
+    # co-resident pairs: per CU, sorted starts
+    cuid = cu >> 8
+    first = {}
+    for i in order:
+        first.setdefault(int(cuid[i]), []).append(i)
+    lens = np.array([len(v) for v in first.values()])
+    print('  workgroups per CU: min %d median %d max %d' % (lens.min(), np.median(lens), lens.max()))
+    d = [us[v[1], 1] - us[v[0], 1] for v in first.values() if len(v) > 1]
+    print('  main-loop start of the 2nd minus the 1st workgroup on a CU: median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(d, [50, 10, 90])))
+    # per-CU timelines of a few CUs
+    for c in sorted(first)[:6]:
+        print('  CU %05x: ' % c + '  '.join('[%.0f %.0f %.0f %.0f]' % tuple(us[i]) for i in first[c]))
+    if a.dump:
+        json.dump({'us': us.tolist(), 'cu': cu.tolist()}, open(a.dump, 'w'))
+
+
+if __name__ == '__main__':
+    main()

@@ -205,12 +205,14 @@ def test_benchmark_shape_properties():
     assert np.sqrt(np.mean((y1[0] - y[5]) ** 2)) < 1e-6 * np.sqrt(np.mean(y[5] ** 2))
     from gcc_nmf_amd import _hip
     lib = _hip.lib()
-    assert lib.gccnmf_set_tuning(2, 1) == 0
-    try:
-        y1 = e1.separate(xs[5])
-    finally:
-        lib.gccnmf_set_tuning(2, 0)
-    assert np.array_equal(y1[0], y[5])
+    for policy in (1, 2):                 # same GEMM tile for both batch sizes -> bit-identical
+        assert lib.gccnmf_set_tuning(2, policy) == 0
+        try:
+            y8 = e.separate(xs)
+            y1 = e1.separate(xs[5])
+        finally:
+            lib.gccnmf_set_tuning(2, 0)
+        assert np.array_equal(y1[0], y8[5]), policy
 
 
 def test_pcm16_ingest_and_egress(dev1, tmp_path):
