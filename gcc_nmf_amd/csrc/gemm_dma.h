@@ -110,6 +110,197 @@ struct GemmFrag<false, NT, ROWS> {
     }
 };
 
+// ---- lean epilogues -----------------------------------------------------------------------------------------------------
+// Beside a co-resident workgroup that is in its main loop, every instruction of an epilogue costs several times its
+// stand-alone issue time (measured with the per-workgroup timeline, scripts/ktrace.py: the W.H epilogue takes 13 us when
+// the CU is otherwise idle and 36 us next to a main loop -- with or without its loads and stores -- and the main loop
+// next to it drops to 65 % of the matrix-pipe rate).  So the epilogues of FULL tiles (all 32 rows < M, all 64 columns < N:
+// every tile of the benchmark shape but the last column tile of a file) are written for instruction count:
+//   * rows are addressed through a wave-uniform row pointer (SALU arithmetic, SGPR base of the global access) plus ONE
+//     per-lane element offset: no per-element 64-bit VALU address arithmetic, clamps or predicates;
+//   * x / d with a divisor that is constant per lane or per row multiplies by the correctly rounded 1/d (<= 1 ulp from
+//     the IEEE quotient); V / (W.H) is v_rcp_f32 + one Newton correction through the exact fma residual (4 instructions
+//     instead of the ~10 of the IEEE sequence; correctly rounded except for rare 1-ulp cases, no denormal/overflow fix-up).
+// Ragged tiles take the generic gemm_epilogue_pair / gemm_epilogue_update_w of gemm_mfma.h.
+__device__ __forceinline__ float gemm_div_fast(float v, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = v * r;
+    return fmaf(fmaf(-d, q, v), r, q);
+}
+
+// Raw buffer accesses: address = descriptor base (SGPRs) + soffset (SGPR, the row) + voffset (VGPR, the lane) + immediate.
+typedef int gemm_i32x4 __attribute__((ext_vector_type(4)));
+__device__ float gemm_buffer_load(gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ gemm_f32x4 gemm_buffer_load4(gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void gemm_buffer_store(float data, gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ __forceinline__ gemm_i32x4 gemm_buffer_rsrc(const void* wave_uniform_base) {
+    const unsigned long long a = (unsigned long long)wave_uniform_base;
+    gemm_i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);     // stride 0
+    r.z = -1;                                                                    // num_records: unbounded (bytes)
+    r.w = 0x00020000;                                                            // gfx9 raw dword buffer
+    return r;
+}
+
+// One tile pair's epilogue inputs, loaded by load() and consumed by finish(): two instances alternate so that the loads of
+// pair m+1 are in flight while pair m is computed and stored (one exposed memory round trip per wave instead of four).
+// Per-row factors (EPI_UPDH: scale / (column sum + alpha + eps); the rank-1 tail column) are NOT loaded here: the
+// workgroup puts them into LDS once, before its main loop (s_rowvec), and finish() reads them as 16-byte groups.
+template <int EPI>
+struct GemmEpiloguePair {
+    static_assert(EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH, "");
+    float xa[16], xb[16];          // EPI_DIV: V; EPI_UPDH: old H
+
+    // row_u: first row of the pair (wave-uniform); lanes hold rows row_u + 8g + 4hh + (0..3), g = 0..3, columns col_a, col_a + 32
+    __device__ __forceinline__ void load(const GemmArgs& p, int file, int row_u, int hh, int col_a) {
+        if (EPI == EPI_DIV || EPI == EPI_UPDH) {
+            const int lo = 4 * (4 * hh * p.ldc + col_a);           // lane offset (bytes) from the wave-uniform row start
+            const int ro = 4 * row_u * p.ldc, rstep = 4 * p.ldc;   // row offsets (bytes) inside one file: < 2^31 for any sane size
+            const gemm_i32x4 X = gemm_buffer_rsrc(EPI == EPI_DIV ? p.E0 + file * p.sE0 : p.C + file * p.sC);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ro + ((r & 3) + 8 * (r >> 2)) * rstep;
+                xa[r] = gemm_buffer_load(X, lo, so, 0);
+                xb[r] = gemm_buffer_load(X, lo + 128, so, 0);
+            }
+        }
+    }
+
+    // s_rowvec: [0, 512) = tail column of A (0 without a rank-1 tail), [512, 1024) = EPI_UPDH row factor, indexed by the row
+    // inside the workgroup tile; tile_row = row_u - (first row of the workgroup tile)
+    __device__ __forceinline__ void finish(const GemmArgs& p, int file, int row_u, int tile_row, int hh, int col_a, float ba, float bb,
+                                           const float* s_rowvec, const f32x16& acc_a, const f32x16& acc_b) const {
+        const int lo = 4 * (4 * hh * p.ldc + col_a);
+        const int ro = 4 * row_u * p.ldc, rstep = 4 * p.ldc;
+        const gemm_i32x4 C = gemm_buffer_rsrc(p.C + file * p.sC);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            gemm_f32x4 tav = {0.f, 0.f, 0.f, 0.f}, gv = tav;
+            if (EPI == EPI_STORE || EPI == EPI_UPDH) tav = *(const gemm_f32x4*)(s_rowvec + tile_row + 8 * g + 4 * hh);
+            if (EPI == EPI_UPDH) gv = *(const gemm_f32x4*)(s_rowvec + 512 + tile_row + 8 * g + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * g + i;
+                const int so = ro + (i + 8 * g) * rstep;
+                float ua = acc_a[r], ub = acc_b[r];
+                if (EPI == EPI_STORE || EPI == EPI_UPDH) {     // last reduction index as one fmaf per element, in chain order (the final k)
+                    ua = fmaf(tav[i], ba, ua);
+                    ub = fmaf(tav[i], bb, ub);
+                }
+                if (EPI == EPI_DIV) {
+                    ua = gemm_div_fast(xa[r], ua);
+                    ub = gemm_div_fast(xb[r], ub);
+                } else if (EPI == EPI_UPDH) {
+                    ua = (xa[r] * ua) * gv[i];
+                    ub = (xb[r] * ub) * gv[i];
+                }
+                gemm_buffer_store(ua, C, lo, so, 0);
+                gemm_buffer_store(ub, C, lo + 128, so, 0);
+            }
+        }
+    }
+};
+
+// EPI_UPDW for full tiles (every wave entirely inside or entirely outside M, all 64 atoms < N): gemm_epilogue_update_w of
+// gemm_mfma.h with row-pointer addressing and the two per-atom divisors (row sum of H, atom norm) turned into one IEEE
+// reciprocal per lane each.
+template <bool TAIL>
+__device__ __forceinline__ void gemm_epilogue_update_w_full(const GemmArgs& p, int file, int col0, int tid, int wm, int l31, int hh,
+                                                            bool wave_active, f32x16 (&acc)[4][2], float tail_acc, float rowsum_acc,
+                                                            float* smem) {
+    float* s_rs = smem;              // [64]     rowsum of H per atom
+    float* s_tail = smem + 64;       // [4][64]  partial dot products of the tail row
+    float* s_red = smem + 320;       // [5][64]  per-wave (+ tail row) partial column reductions
+    float* s_norm = smem + 640;      // [64]
+    float rs = rowsum_acc;
+    rs += __shfl_xor(rs, 1);
+    rs += __shfl_xor(rs, 2);
+    if ((tid & 3) == 0) s_rs[tid >> 2] = rs;
+    if (TAIL) s_tail[tid] = tail_acc;
+    __syncthreads();
+    const int ca = l31, cb = l31 + 32;
+    const float ira = 1.0f / s_rs[ca], irb = 1.0f / s_rs[cb];
+    const gemm_i32x4 W = gemm_buffer_rsrc(p.C + file * p.sC);
+    const int lo = 4 * (4 * hh * p.ldc + col0 + l31), rstep = 4 * p.ldc;
+    float ssa = 0.f, ssb = 0.f;
+    if (wave_active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ro = (wm * 128 + m * 32) * rstep;
+            float wa[16], wb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ro + ((r & 3) + 8 * (r >> 2)) * rstep;
+                wa[r] = gemm_buffer_load(W, lo, so, 0);
+                wb[r] = gemm_buffer_load(W, lo + 128, so, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ta = wa[r] * (acc[m][0][r] * ira), tb = wb[r] * (acc[m][1][r] * irb);
+                acc[m][0][r] = ta;
+                acc[m][1][r] = tb;
+                ssa = fmaf(ta, ta, ssa);
+                ssb = fmaf(tb, tb, ssb);
+            }
+        }
+    }
+    ssa += __shfl_xor(ssa, 32);
+    ssb += __shfl_xor(ssb, 32);
+    if (hh == 0) {
+        s_red[wm * 64 + ca] = ssa;
+        s_red[wm * 64 + cb] = ssb;
+    }
+    float wt_tail = 0.f;
+    float* Wp = p.C + file * p.sC;
+    if (tid < 64) {
+        if (TAIL) {
+            const float u = (s_tail[tid] + s_tail[64 + tid]) + (s_tail[128 + tid] + s_tail[192 + tid]);
+            wt_tail = Wp[(long)p.tail_row * p.ldc + col0 + tid] * (u / s_rs[tid]);
+        }
+        s_red[256 + tid] = wt_tail * wt_tail;
+    }
+    __syncthreads();
+    if (tid < 64) s_norm[tid] = sqrtf(((s_red[tid] + s_red[64 + tid]) + (s_red[128 + tid] + s_red[192 + tid])) + s_red[256 + tid]);
+    __syncthreads();
+    const float ina = 1.0f / s_norm[ca], inb = 1.0f / s_norm[cb];
+    float csa = 0.f, csb = 0.f;
+    if (wave_active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ro = (wm * 128 + m * 32) * rstep;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ro + ((r & 3) + 8 * (r >> 2)) * rstep;
+                const float na = acc[m][0][r] * ina, nb = acc[m][1][r] * inb;
+                gemm_buffer_store(na, W, lo, so, 0);
+                gemm_buffer_store(nb, W, lo + 128, so, 0);
+                csa += na;
+                csb += nb;
+            }
+        }
+    }
+    csa += __shfl_xor(csa, 32);
+    csb += __shfl_xor(csb, 32);
+    if (hh == 0) {
+        s_red[wm * 64 + ca] = csa;
+        s_red[wm * 64 + cb] = csb;
+    }
+    if (tid < 64) {
+        float wn_tail = 0.f;
+        if (TAIL) {
+            wn_tail = wt_tail / s_norm[tid];
+            Wp[(long)p.tail_row * p.ldc + col0 + tid] = wn_tail;
+        }
+        s_red[256 + tid] = wn_tail;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        p.out_colsum[file * p.s_out + col0 + tid] = ((s_red[tid] + s_red[64 + tid]) + (s_red[128 + tid] + s_red[192 + tid])) + s_red[256 + tid];
+        p.out_norm[file * p.s_out + col0 + tid] = s_norm[tid];
+    }
+}
+
 template <bool A_KC, bool B_KC, int EPI, bool TAIL>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     constexpr int BK = 16, TM = 4, BM = 512, BN = 64;
@@ -117,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
     constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);   // K1 (R = V / (W.(s*H))) carries a lazy row scale on its B operand
     __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
+    __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * BM : 4];   // lean epilogue row factors
 
     const int tiles = p.tiles_m * p.tiles_n;
     int file, tile;
@@ -129,7 +321,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
     }
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    // (the integer divisions above run on the VALU: without the readfirstlanes every value derived from file / tile -- all
+    // row pointers, descriptors and scalar offsets below -- stays in VGPRs and each buffer access becomes a waterfall loop)
+    file = __builtin_amdgcn_readfirstlane(file);
+    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = __builtin_amdgcn_readfirstlane(tile) - tm * p.tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
@@ -319,6 +514,18 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(1, e), acc[m][1], 0, 0, 0);
     };
 
+    // row factors of the lean epilogue (visible after the prologue barrier; read only after the main loop)
+    if constexpr (EPI == EPI_STORE || EPI == EPI_UPDH) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = tid + 256 * i, row = min(row0 + lr, p.M - 1);
+            s_rowvec[lr] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
+            if (EPI == EPI_UPDH) {
+                const float rd = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
+                s_rowvec[512 + lr] = p.E1 ? p.E1[file * p.sE1 + row] * rd : rd;
+            }
+        }
+    }
     // prologue: tile 0 -> buffer 0, group 0 of tile 0 into registers
 #pragma unroll
     for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
@@ -429,11 +636,33 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
     };
+#ifdef GEMM_DMA_PREFETCH
+    const int kt_pf = max(0, (nkt - GEMM_DMA_PREFETCH) & ~1);
+#endif
     for (int kt = 0; kt < nkt; kt += 2) {
+#ifdef GEMM_DMA_PREFETCH
+        // pull the tile the epilogue will read (V / old H: read once per launch, always an HBM miss) into L2 a few k-tiles
+        // before the main loop ends: one dword per 128-byte line, 4 loads per wave cover its 128 x 64 outputs
+        if constexpr (EPI == EPI_DIV || EPI == EPI_UPDH) {
+            if (kt == kt_pf && wave_active) {
+                const float* X = (EPI == EPI_DIV ? p.E0 + file * p.sE0 : p.C + file * p.sC) + (long)(row0 + wm * 128) * p.ldc + col0;
+                const gemm_i32x4 rs = gemm_buffer_rsrc(X);
+                const int vo = 4 * ((lane >> 1) * p.ldc + (lane & 1) * 32), so = 4 * 32 * p.ldc;
+                float d0;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\tbuffer_load_dword %0, %1, %2, %3 offen\n\tbuffer_load_dword %0, %1, %2, %4 offen\n\tbuffer_load_dword %0, %1, %2, %5 offen"
+                             : "=&v"(d0) : "v"(vo), "s"(rs), "s"(so), "s"(2 * so), "s"(3 * so));
+            }
+        }
+#endif
         step(std::integral_constant<int, 0>{}, kt);
         if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
     }
     __syncthreads();                      // the epilogues reuse the staging buffers
+#ifndef GEMM_DMA_NO_EPI_PRIO
+    // The epilogue is a few thousand short instructions next to the other workgroup's 64-cycle MFMAs: at equal priority it
+    // gets an issue slot now and then and takes 3x its stand-alone time while the slot it occupies does no matrix work.
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef GEMM_DMA_PROBE
     if (p.trace && lane == 0) {
 #pragma unroll
@@ -443,7 +672,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 
     if (EPI == EPI_UPDW) {
-        gemm_epilogue_update_w<TAIL>(p, file, col0, tid, wm, l31, hh, acc, tail_acc, rowsum_acc, smem);
+        // launch_rht_update_w guarantees M % 128 == 0 and N % 64 == 0 (a second, generic variant in this kernel would
+        // double the live ranges of the accumulators and spill the main loop)
+        gemm_epilogue_update_w_full<TAIL>(p, file, col0, tid, wm, l31, hh, wave_active, acc, tail_acc, rowsum_acc, smem);
         if (p.trace) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -452,9 +683,34 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         return;
     }
     if (wave_active) {
+        const int row_w = row0 + wm * 128;                          // wave-uniform
+        bool lean = false;
+        if constexpr (EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH) {
+            lean = (col0 + BN <= p.N) && (row_w + 128 <= p.M);      // all four tile pairs of the wave are full
+            if (lean) {
+                GemmEpiloguePair<EPI> e0, e1;
+                const int ca = col0 + l31, tr = wm * 128;
+                e0.load(p, file, row_w, hh, ca);
+                e1.load(p, file, row_w + 32, hh, ca);
+                float ba = 0.f, bb = 0.f;
+                if (EPI != EPI_DIV && p.ktailA) {
+                    ba = p.ktailB[file * p.s_ktailB + ca];
+                    bb = p.ktailB[file * p.s_ktailB + ca + 32];
+                }
+                e0.finish(p, file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1]);
+                if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+                e0.load(p, file, row_w + 64, hh, ca);
+                e1.finish(p, file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1]);
+                e1.load(p, file, row_w + 96, hh, ca);
+                e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1]);
+                e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1]);
+                if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+        if (!lean) {
 #pragma unroll
-        for (int m = 0; m < TM; ++m)
-            gemm_epilogue_pair<EPI>(p, file, row0 + wm * 128 + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
+            for (int m = 0; m < TM; ++m) gemm_epilogue_pair<EPI>(p, file, row_w + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
+        }
     }
     if (TAIL) {
         if (do_tail) {

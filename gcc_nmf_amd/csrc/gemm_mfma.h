@@ -140,10 +140,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int file, int r
 // load -> use -> store chain would serialise 128 memory round trips per lane (the in-place H update cannot
 // be reordered by the compiler) and cost as much as the whole k-loop.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, f32x16& acc_a,
-                                                   f32x16& acc_b) {
+__device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, const f32x16& acc_in_a,
+                                                   const f32x16& acc_in_b) {
     const int col_b = col_a + 32;
     const bool ok_a = gemm_col_valid<EPI>(p, col_a), ok_b = gemm_col_valid<EPI>(p, col_b);
+    // (the accumulators are never written here: a second code path that modifies them next to the lean epilogues of
+    // gemm_dma.h doubles their live ranges and spills)
+    float acc_a[16], acc_b[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_a[r] = acc_in_a[r];
+        acc_b[r] = acc_in_b[r];
+    }
     if (EPI == EPI_STORE || EPI == EPI_UPDH) {
         if (p.ktailA) {   // last reduction index as one fmaf per element, in chain order (it is the final k)
             const float* __restrict__ ta = p.ktailA + file * p.s_ktailA;
@@ -184,13 +192,8 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
         for (int r = 0; r < 16; ++r) {
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             if (row < p.M) {
-#ifdef GEMM_FAST_DIV
-                if (ok_a) C[(long)row * p.ldc + col_a] = va[r] * __builtin_amdgcn_rcpf(acc_a[r]);
-                if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] * __builtin_amdgcn_rcpf(acc_b[r]);
-#else
                 if (ok_a) C[(long)row * p.ldc + col_a] = va[r] / acc_a[r];
                 if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] / acc_b[r];
-#endif
             }
         }
     } else if (EPI == EPI_UPDH) {
@@ -212,14 +215,8 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             const float d = den[r] + p.alpha + p.eps;
             if (row < p.M) {
-#ifdef GEMM_FAST_DIV
-                const float rd = __builtin_amdgcn_rcpf(d);
-                if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] * rd);
-                if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] * rd);
-#else
                 if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] / d);
                 if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] / d);
-#endif
             }
         }
     } else {  // EPI_PHASE: one tile at a time (X is two registers per element)

@@ -325,7 +325,9 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
     a.tail_row = g.F - 1;
     a.C = W; a.sC = g.sW; a.ldc = g.Kp;
     a.out_colsum = colsumW; a.out_norm = hscale; a.s_out = g.Kp;
-    if (gccnmf_tune_dma)
+    // the LDS-DMA kernel carries only the full-tile form of this epilogue (every wave entirely inside or outside M, no
+    // ragged atom tile); anything else takes the register-staged kernel with the generic one
+    if (gccnmf_tune_dma && (a.M & 127) == 0 && (a.N & 63) == 0)
         return g.tail ? gccnmf_launch_gemm_dma<true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm_dma<true, true, EPI_UPDW, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, false>(a, s);
 }

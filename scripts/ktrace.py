@@ -81,6 +81,10 @@ def main():
     print('  start offset wait  (t1-t0): median %.1f  p90 %.1f  max %.1f us' % tuple(np.percentile(us[:, 1] - us[:, 0], [50, 90, 100])))
     print('  main loop          (t2-t1): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 2] - us[:, 1], [50, 10, 90])))
     print('  epilogue           (t3-t2): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 3] - us[:, 2], [50, 10, 90])))
+    if t[:, 5].max() > 0:
+        e5, e6 = (t[:, 5] - t0) / 100.0, (t[:, 6] - t0) / 100.0
+        print('    lean epilogue, wave 0: first pair done after %.1f us, all stores issued after %.1f us, stores drained after %.1f us (medians)' % (
+            np.median(e5 - us[:, 2]), np.median(e6 - us[:, 2]), np.median(us[:, 3] - us[:, 2])))
     # how many workgroups are in their epilogue / main loop over time
     edges = np.arange(0, us[:, 3].max() + 10, 10.0)
     in_epi = [(np.sum((us[:, 2] <= x) & (us[:, 3] > x)), np.sum((us[:, 1] <= x) & (us[:, 2] > x))) for x in edges]
