@@ -329,26 +329,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
 
-    // Phase offset between the two workgroups that share a CU.  All workgroups of a launch are equally long, so without it
-    // every CU runs main loop | main loop and then epilogue | epilogue: the whole chip bursts its V/H/R epilogue traffic
-    // into HBM at the same moments while every matrix pipe idles.  The SECOND workgroup to arrive on a CU in this launch
-    // (found by stamping a per-CU slot, keyed by the hardware CU id -- speed only, nothing depends on placement) sleeps
-    // for a fraction of a main loop; the first one meanwhile has the matrix pipe to itself (2x rate), nothing is lost,
-    // and from then on one workgroup's epilogue overlaps the other's MFMAs.  Later arrivals start immediately.
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
-    if (p.stagger_loops > 0) {
-        if (tid == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);           // HW_REG_HW_ID: cu_id/sh_id/se_id in [15:8]
-            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);          // HW_REG_XCC_ID[3:0]
-            const int cu = (int)(((xcc & 15u) << 8) | ((hw >> 8) & 0xffu));
-            if (atomicExch(&p.cu_table[cu], p.epoch) == p.epoch && atomicExch(&p.cu_table[4096 + cu], p.epoch) != p.epoch) {
-                for (int i = 0; i < p.stagger_loops; ++i) __builtin_amdgcn_s_sleep(127);
-            }
-        }
-        __syncthreads();
-    }
     if (p.trace && tid == 0) {
-        p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 0] = p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
     }
     const int wm = wave, wn = 0;
@@ -636,24 +618,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
     };
-#ifdef GEMM_DMA_PREFETCH
-    const int kt_pf = max(0, (nkt - GEMM_DMA_PREFETCH) & ~1);
-#endif
     for (int kt = 0; kt < nkt; kt += 2) {
-#ifdef GEMM_DMA_PREFETCH
-        // pull the tile the epilogue will read (V / old H: read once per launch, always an HBM miss) into L2 a few k-tiles
-        // before the main loop ends: one dword per 128-byte line, 4 loads per wave cover its 128 x 64 outputs
-        if constexpr (EPI == EPI_DIV || EPI == EPI_UPDH) {
-            if (kt == kt_pf && wave_active) {
-                const float* X = (EPI == EPI_DIV ? p.E0 + file * p.sE0 : p.C + file * p.sC) + (long)(row0 + wm * 128) * p.ldc + col0;
-                const gemm_i32x4 rs = gemm_buffer_rsrc(X);
-                const int vo = 4 * ((lane >> 1) * p.ldc + (lane & 1) * 32), so = 4 * 32 * p.ldc;
-                float d0;
-                asm volatile("buffer_load_dword %0, %1, %2, 0 offen\n\tbuffer_load_dword %0, %1, %2, %3 offen\n\tbuffer_load_dword %0, %1, %2, %4 offen\n\tbuffer_load_dword %0, %1, %2, %5 offen"
-                             : "=&v"(d0) : "v"(vo), "s"(rs), "s"(so), "s"(2 * so), "s"(3 * so));
-            }
-        }
-#endif
         step(std::integral_constant<int, 0>{}, kt);
         if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
     }
@@ -756,21 +721,6 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
         grid = a.batch * tiles;
     }
     a.trace = (gccnmf_trace_buf && 5 * grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;   // timeline + 4 per-wave probe rows
-    // phase offset of co-resident workgroups: only worth it when every CU gets at least two workgroups, and measured to
-    // pay only for the fused W update, whose epilogue is the longest (R.H^T 0.788 -> 0.748 ms at 40 %; W.H, W^T.R unchanged)
-    a.stagger_loops = 0;
-    a.cu_table = nullptr;
-    if (gccnmf_tune_stagger > 0 && grid >= 512 && EPI == EPI_UPDW) {
-        static int* table = nullptr;
-        static int epoch = 0;
-        if (!table) {
-            if (hipMalloc(&table, 2 * 4096 * sizeof(int)) != hipSuccess || hipMemset(table, 0, 2 * 4096 * sizeof(int)) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-        }
-        a.cu_table = table;
-        a.epoch = ++epoch;
-        const int nkt = gccnmf_ceil_div(a.Kd, 16);
-        a.stagger_loops = (int)((long)nkt * 8192 * gccnmf_tune_stagger / 100 / (127 * 64));     // shared-pipe main loop = 8192 cycles per k-tile
-    }
     hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL>), dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;

@@ -43,7 +43,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 extern int gccnmf_tune_ablate;
 extern long long* gccnmf_trace_buf;
 extern int gccnmf_trace_blocks;
-extern int gccnmf_tune_stagger;    // percent of one workgroup's main loop by which the 2nd workgroup on a CU starts late (gemm_dma.h)
 
 enum GemmEpilogue {
     EPI_STORE = 0,   // C[row][col] = acc
@@ -86,8 +85,6 @@ struct GemmArgs {
     long sX;
     float alpha, eps;
     int T, Tp, Fp, ldv;        // EPI_PHASE geometry
-    int* cu_table;             // gemm_dma.h phase offset: per-CU arrival stamps, launch stamp, s_sleep(127) rounds for the 2nd arrival
-    int epoch, stagger_loops;
     long long* trace;          // debug: per-workgroup timeline, 8 x int64 per block (gccnmf_debug_set_trace)
 };
 
@@ -462,7 +459,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
     }
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    // the integer divisions run on the VALU; pin their (wave-uniform) results to SGPRs so that the operand / output base
+    // pointers derived from them are scalar arithmetic instead of per-lane 64-bit VALU adds
+    file = __builtin_amdgcn_readfirstlane(file);
+    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = __builtin_amdgcn_readfirstlane(tile) - tm * p.tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
 
     const int tid = threadIdx.x;

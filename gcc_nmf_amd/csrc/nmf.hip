@@ -17,7 +17,6 @@ int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage 
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
-int gccnmf_tune_stagger = 40;      // start offset of the 2nd workgroup on a CU, percent of one main loop (gemm_dma.h)
 
 extern "C" {
 int gccnmf_version(void) { return 101; }
@@ -33,10 +32,6 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 3) {
         gccnmf_tune_dma = value ? 1 : 0;
-        return GCCNMF_OK;
-    }
-    if (key == 4 && value >= 0 && value <= 100) {
-        gccnmf_tune_stagger = value;
         return GCCNMF_OK;
     }
     return GCCNMF_ERR_ARG;

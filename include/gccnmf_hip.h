@@ -45,9 +45,7 @@ int gccnmf_version(void);
  * time goes' quotes these).  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
  * 2 always the 128x64 small-batch tile (results stay valid; used by the tests to cover both paths at any size).
  * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
- * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs).
- * key 4: start offset of the second workgroup to arrive on a CU, in percent of one main loop, for the fused R.H^T + W-update
- * launch (default 40, 0 = off; timing only, results are unaffected). */
+ * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs). */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -185,7 +183,7 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
                             int localization_window, int frames_mode, void* stream);
 
 /* Debug: per-workgroup timeline of the LDS-DMA GEMM launches (device buffer of 8 x int64 per workgroup: s_memrealtime
- * [100 MHz] at entry, after the start offset, after the main loop, after the epilogue; [4] = xcc_id<<16 | HW_ID[15:0]).
+ * [100 MHz] at entry (slots 0 and 1), after the main loop, after the epilogue; [4] = xcc_id<<16 | HW_ID[15:0]).
  * Recorded for launches of at most `blocks` workgroups while buf != NULL (scripts/kbench.py --trace). */
 int gccnmf_debug_set_trace(long long* buf, int blocks);
 

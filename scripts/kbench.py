@@ -24,7 +24,6 @@ def main():
     ap.add_argument('--flags', type=int, default=0)
     ap.add_argument('--ablate', type=int, default=0)
     ap.add_argument('--dma', type=int, default=1)
-    ap.add_argument('--stagger', type=int, default=-1)
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
@@ -32,8 +31,6 @@ def main():
     lib = _hip.lib()
     lib.gccnmf_set_tuning(1, a.ablate)
     lib.gccnmf_set_tuning(3, a.dma)
-    if a.stagger >= 0:
-        lib.gccnmf_set_tuning(4, a.stagger)
     F, T, K, B = 513, a.T, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N

@@ -2,7 +2,7 @@
 """Per-workgroup timeline of one KL-NMF GEMM launch at the headline shape (gccnmf_debug_set_trace): when each workgroup
 started, left its main loop and finished its epilogue, and on which CU.
 
-    python scripts/ktrace.py [--stage 1] [--stagger 0] [--files 64] > gpurun_out/trace.json
+    python scripts/ktrace.py [--stage 1] [--files 64] [--probe] > gpurun_out/trace.json
 """
 import argparse
 import json
@@ -19,7 +19,6 @@ def main():
     ap.add_argument('--files', type=int, default=64)
     ap.add_argument('--K', type=int, default=1024)
     ap.add_argument('--stage', type=int, default=1)
-    ap.add_argument('--stagger', type=int, default=0)
     ap.add_argument('--dump', default='')
     ap.add_argument('--probe', action='store_true', help='library built with -DGEMM_DMA_PROBE: per-phase cycles of the k-tile')
     a = ap.parse_args()
@@ -27,7 +26,6 @@ def main():
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
-    lib.gccnmf_set_tuning(4, a.stagger)
     F, T, K, B = 513, 622, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N
@@ -77,8 +75,7 @@ def main():
     us = (t[:, :4] - t0) / 100.0                     # 100 MHz -> microseconds
     cu = t[:, 4]
     order = np.argsort(us[:, 0])
-    print('stage %d, stagger %d: %d workgroups on %d distinct CUs, launch span %.1f us' % (a.stage, a.stagger, len(t), len(np.unique(cu >> 8)), us[:, 3].max()))
-    print('  start offset wait  (t1-t0): median %.1f  p90 %.1f  max %.1f us' % tuple(np.percentile(us[:, 1] - us[:, 0], [50, 90, 100])))
+    print('stage %d: %d workgroups on %d distinct CUs, launch span %.1f us' % (a.stage, len(t), len(np.unique(cu >> 8)), us[:, 3].max()))
     print('  main loop          (t2-t1): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 2] - us[:, 1], [50, 10, 90])))
     print('  epilogue           (t3-t2): median %.1f  p10 %.1f  p90 %.1f us' % tuple(np.percentile(us[:, 3] - us[:, 2], [50, 10, 90])))
     if t[:, 5].max() > 0:
