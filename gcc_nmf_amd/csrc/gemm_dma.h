@@ -133,12 +133,14 @@ typedef int gemm_i32x4 __attribute__((ext_vector_type(4)));
 __device__ float gemm_buffer_load(gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ gemm_f32x4 gemm_buffer_load4(gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ void gemm_buffer_store(float data, gemm_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
-__device__ __forceinline__ gemm_i32x4 gemm_buffer_rsrc(const void* wave_uniform_base) {
+// bytes: extent of the addressed matrix; accesses beyond it (the padding columns of a ragged last tile when the row pitch
+// is not padded to the tile) read 0 / are dropped by the hardware range check
+__device__ __forceinline__ gemm_i32x4 gemm_buffer_rsrc(const void* wave_uniform_base, long bytes = 0x7fffffffL) {
     const unsigned long long a = (unsigned long long)wave_uniform_base;
     gemm_i32x4 r;
     r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
     r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);     // stride 0
-    r.z = -1;                                                                    // num_records: unbounded (bytes)
+    r.z = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffffL ? bytes : 0x7fffffffL));   // num_records (bytes)
     r.w = 0x00020000;                                                            // gfx9 raw dword buffer
     return r;
 }
@@ -153,11 +155,12 @@ struct GemmEpiloguePair {
     float xa[16], xb[16];          // EPI_DIV: V; EPI_UPDH: old H
 
     // row_u: first row of the pair (wave-uniform); lanes hold rows row_u + 8g + 4hh + (0..3), g = 0..3, columns col_a, col_a + 32
-    __device__ __forceinline__ void load(const GemmArgs& p, int file, int row_u, int hh, int col_a) {
+    // cb: bytes of one file's V / C matrix (descriptor range)
+    __device__ __forceinline__ void load(const GemmArgs& p, int file, int row_u, int hh, int col_a, long cb) {
         if (EPI == EPI_DIV || EPI == EPI_UPDH) {
             const int lo = 4 * (4 * hh * p.ldc + col_a);           // lane offset (bytes) from the wave-uniform row start
             const int ro = 4 * row_u * p.ldc, rstep = 4 * p.ldc;   // row offsets (bytes) inside one file: < 2^31 for any sane size
-            const gemm_i32x4 X = gemm_buffer_rsrc(EPI == EPI_DIV ? p.E0 + file * p.sE0 : p.C + file * p.sC);
+            const gemm_i32x4 X = gemm_buffer_rsrc(EPI == EPI_DIV ? p.E0 + file * p.sE0 : p.C + file * p.sC, cb);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int so = ro + ((r & 3) + 8 * (r >> 2)) * rstep;
@@ -169,11 +172,14 @@ struct GemmEpiloguePair {
 
     // s_rowvec: [0, 512) = tail column of A (0 without a rank-1 tail), [512, 1024) = EPI_UPDH row factor, indexed by the row
     // inside the workgroup tile; tile_row = row_u - (first row of the workgroup tile)
+    // oka / okb: this lane's column (col_a, col_a + 32) is inside N -- the only predicate of the lean path, two exec-mask
+    // regions per pair (the last column tile of a file is ragged: N = 1244 = 19 x 64 + 28)
     __device__ __forceinline__ void finish(const GemmArgs& p, int file, int row_u, int tile_row, int hh, int col_a, float ba, float bb,
-                                           const float* s_rowvec, const f32x16& acc_a, const f32x16& acc_b) const {
+                                           const float* s_rowvec, const f32x16& acc_a, const f32x16& acc_b, bool oka, bool okb, long cb) const {
         const int lo = 4 * (4 * hh * p.ldc + col_a);
         const int ro = 4 * row_u * p.ldc, rstep = 4 * p.ldc;
-        const gemm_i32x4 C = gemm_buffer_rsrc(p.C + file * p.sC);
+        const gemm_i32x4 C = gemm_buffer_rsrc(p.C + file * p.sC, cb);
+        float ua[16], ub[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             gemm_f32x4 tav = {0.f, 0.f, 0.f, 0.f}, gv = tav;
@@ -182,22 +188,28 @@ struct GemmEpiloguePair {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
-                const int so = ro + (i + 8 * g) * rstep;
-                float ua = acc_a[r], ub = acc_b[r];
+                ua[r] = acc_a[r];
+                ub[r] = acc_b[r];
                 if (EPI == EPI_STORE || EPI == EPI_UPDH) {     // last reduction index as one fmaf per element, in chain order (the final k)
-                    ua = fmaf(tav[i], ba, ua);
-                    ub = fmaf(tav[i], bb, ub);
+                    ua[r] = fmaf(tav[i], ba, ua[r]);
+                    ub[r] = fmaf(tav[i], bb, ub[r]);
                 }
                 if (EPI == EPI_DIV) {
-                    ua = gemm_div_fast(xa[r], ua);
-                    ub = gemm_div_fast(xb[r], ub);
+                    ua[r] = gemm_div_fast(xa[r], ua[r]);
+                    ub[r] = gemm_div_fast(xb[r], ub[r]);
                 } else if (EPI == EPI_UPDH) {
-                    ua = (xa[r] * ua) * gv[i];
-                    ub = (xb[r] * ub) * gv[i];
+                    ua[r] = (xa[r] * ua[r]) * gv[i];
+                    ub[r] = (xb[r] * ub[r]) * gv[i];
                 }
-                gemm_buffer_store(ua, C, lo, so, 0);
-                gemm_buffer_store(ub, C, lo + 128, so, 0);
             }
+        }
+        if (oka) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gemm_buffer_store(ua[r], C, lo, ro + ((r & 3) + 8 * (r >> 2)) * rstep, 0);
+        }
+        if (okb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gemm_buffer_store(ub[r], C, lo + 128, ro + ((r & 3) + 8 * (r >> 2)) * rstep, 0);
         }
     }
 };
@@ -623,11 +635,6 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
     }
     __syncthreads();                      // the epilogues reuse the staging buffers
-#ifndef GEMM_DMA_NO_EPI_PRIO
-    // The epilogue is a few thousand short instructions next to the other workgroup's 64-cycle MFMAs: at equal priority it
-    // gets an issue slot now and then and takes 3x its stand-alone time while the slot it occupies does no matrix work.
-    __builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef GEMM_DMA_PROBE
     if (p.trace && lane == 0) {
 #pragma unroll
@@ -651,24 +658,26 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         const int row_w = row0 + wm * 128;                          // wave-uniform
         bool lean = false;
         if constexpr (EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH) {
-            lean = (col0 + BN <= p.N) && (row_w + 128 <= p.M);      // all four tile pairs of the wave are full
+            lean = row_w + 128 <= p.M;                              // all four tile pairs of the wave have all their rows
             if (lean) {
                 GemmEpiloguePair<EPI> e0, e1;
                 const int ca = col0 + l31, tr = wm * 128;
-                e0.load(p, file, row_w, hh, ca);
-                e1.load(p, file, row_w + 32, hh, ca);
+                const bool oka = ca < p.N, okb = ca + 32 < p.N;
+                const long cb = 4L * p.ldc * (p.M + (TAIL ? 1 : 0));
                 float ba = 0.f, bb = 0.f;
+                e0.load(p, file, row_w, hh, ca, cb);
+                e1.load(p, file, row_w + 32, hh, ca, cb);
                 if (EPI != EPI_DIV && p.ktailA) {
-                    ba = p.ktailB[file * p.s_ktailB + ca];
-                    bb = p.ktailB[file * p.s_ktailB + ca + 32];
+                    ba = p.ktailB[file * p.s_ktailB + min(ca, p.N - 1)];
+                    bb = p.ktailB[file * p.s_ktailB + min(ca + 32, p.N - 1)];
                 }
-                e0.finish(p, file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1]);
+                e0.finish(p, file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
                 if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-                e0.load(p, file, row_w + 64, hh, ca);
-                e1.finish(p, file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1]);
-                e1.load(p, file, row_w + 96, hh, ca);
-                e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1]);
-                e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1]);
+                e0.load(p, file, row_w + 64, hh, ca, cb);
+                e1.finish(p, file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1], oka, okb, cb);
+                e1.load(p, file, row_w + 96, hh, ca, cb);
+                e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
+                e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
                 if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
             }
         }
