@@ -41,6 +41,9 @@ def parse():
     p.add_argument('--hop', type=int, default=256)
     p.add_argument('--seconds', type=float, default=10.0)
     p.add_argument('--no-xcd-affinity', action='store_true')
+    p.add_argument('--nmf-groups', type=int, default=None,
+                   help='KL-NMF file groups on separate streams (engine default: 2 from 32 files up); 1 = one launch per stage over the '
+                        'whole batch, the configuration the roofline kernel is timed in')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
     p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming'], default='separate',
@@ -202,7 +205,7 @@ def main():
     xs = synthetic_batch(rank * B, B, numSamples=n, sampleRate=sr)          # each rank: its own shard of files
     e = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=a.hop, numTDOAs=128, microphoneSeparationInMetres=1.0,
                      numTargets=3, dictionarySize=K, numIterations=iters, batch=B, device='cuda:%d' % local_rank,
-                     klnmf_flags=1 if a.no_xcd_affinity else 0)
+                     klnmf_flags=1 if a.no_xcd_affinity else 0, nmf_groups=a.nmf_groups)
     g = e.g
     e.upload(xs)                                                             # inputs resident in HBM before timing
 
@@ -242,7 +245,8 @@ def main():
                                '(F=513, T=%d/file), K=%d, %d KL-NMF iters, 128 TDOAs, 3 targets; end-to-end samples-in-HBM -> '
                                'separated waveforms-in-HBM, independent dictionary per file' % (B, a.seconds, a.hop, g.T, K, iters),
                    'files_per_gpu': B, 'frames_per_file': g.T, 'dictionary_size': K, 'nmf_iterations': iters,
-                   'parallelism': 'file-sharded x%d, no data-path collective' % world},
+                   'parallelism': 'file-sharded x%d, no data-path collective' % world,
+                   'nmf_file_groups_per_gpu': e.nmf_groups},
         'tdoa_indexes_as_expected': idx_ok,
     }
 
@@ -266,7 +270,10 @@ def main():
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-                           'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms)}
+                           'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms),
+                           'launch': 'one launch over all %d files on one stream, %d back to back (the timed steps run KL-NMF as %d file '
+                                     'group(s) on separate streams, whose launches overlap in time; rocprofv3 averages of this launch: '
+                                     'python bench.py --nmf-groups 1)' % (B, 20, e.nmf_groups)}
         if pmc and pmc.get('files_per_gpu') == B and pmc.get('dictionary_size') == K and a.seconds == 10.0 and a.hop == 256:
             # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (profiles/README.md), gfx950-corrected
             out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']

@@ -15,14 +15,21 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 echo "== bench"
 timeout 900 python bench.py --gpus 1 --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
 echo "== rocprofv3 kernel stats"
+# (a) the default command: KL-NMF as two file groups on two streams -- the groups' launches overlap in time, so the per-kernel
+#     averages are those of 32-file launches sharing the chip
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --gpus 1 --steps 2 --warmup 1 --skip-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
 echo "rocprof exit $?"; ls -R $OUT/prof | head -20
-find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -30
+find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -8
+# (b) one launch per stage over the whole batch: the configuration bench.py times its roofline kernel in
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_g1 -o bench -- python bench.py --gpus 1 --steps 2 --warmup 1 --skip-cpu-baseline --nmf-groups 1 > $OUT/prof_g1_bench.json 2> $OUT/prof_g1.err
+echo "rocprof (--nmf-groups 1) exit $?"
+find $OUT/prof_g1 -name "*kernel_stats*.csv" | head -1 | xargs -r head -8
+find $OUT/prof_g1 -name "*kernel_trace*.csv" -size +20M -delete
 # keep the merged-back payload small: drop the raw per-dispatch trace if it is huge
 find $OUT/prof -name "*kernel_trace*.csv" -size +20M -delete
 # HBM traffic of the GEMM kernels: separate PMC passes (never combined with the trace domains above)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python bench.py --gpus 1 --steps 1 --warmup 0 --skip-cpu-baseline --skip-roofline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python bench.py --gpus 1 --steps 1 --warmup 0 --skip-cpu-baseline --skip-roofline --nmf-groups 1 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
   echo "pmc $c exit $?"
   find $OUT/pmc_$c -name "*kernel_trace*" -delete
 done

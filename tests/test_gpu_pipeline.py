@@ -242,3 +242,22 @@ def test_pcm16_ingest_and_egress(dev1, tmp_path):
         m = np.max(np.abs(yl[i]))
         expect = O.float2pcm((yl[i] / m * 0.99).astype(np.float32)) if m >= 1 else O.float2pcm(yl[i])
         assert np.abs(loud[i].astype(int) - expect.astype(int)).max() <= 1
+
+
+def test_nmf_file_groups_on_streams_are_bitwise_the_single_stream_result():
+    """The engine runs KL-NMF per file group on separate streams (tail of one group's launches overlaps the head of
+    another's); the mixtures are independent, so the result is bit for bit that of one launch over the whole batch, and a
+    second run of the same engine (stream / event reuse) reproduces it."""
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    xs = synthetic_batch(300, 32, numSamples=32000)
+    kw = dict(dictionarySize=128, numIterations=10, batch=32)
+    e1 = engine(32000, nmf_groups=1, **kw)
+    y1 = e1.separate(xs)
+    for groups in (None, 4):
+        eg = engine(32000, nmf_groups=groups, **kw)
+        assert eg.nmf_groups == (2 if groups is None else groups)             # default: two groups from 32 files up
+        yg = eg.separate(xs)
+        assert np.array_equal(yg, y1) and torch.equal(eg.W, e1.W) and torch.equal(eg.H, e1.H)
+        assert np.array_equal(eg.separate(xs), y1)
+    with pytest.raises(ValueError):
+        engine(32000, nmf_groups=5, **kw)
