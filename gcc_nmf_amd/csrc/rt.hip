@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void rt_gccnmf_kernel(const float2* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const int tau = tt * 32 + l31;
-#pragma unroll 4
         for (int p = 0; p < steps; ++p) {
             const int f = 2 * p + hh;
             float a = 0.f, b = 0.f;
