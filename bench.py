@@ -254,7 +254,14 @@ def main():
         # host float32 samples in -> host float32 waveforms out (PCIe both ways); reported beside `value`, never as `value`
         t1 = time.perf_counter()
         e.separate(xs)
-        out['host_to_host_frames_per_s'] = B * g.T / (time.perf_counter() - t1)
+        out['host_to_host_frames_per_s'] = B * g.T / (time.perf_counter() - t1)           # one batch, copies not overlapped
+        nb = 4
+        for _y in e.separate_batches(xs for _ in range(2)):      # allocates the pinned staging buffers
+            pass
+        t1 = time.perf_counter()
+        for _y in e.separate_batches(xs for _ in range(nb)):
+            pass
+        out['host_to_host_pipelined_frames_per_s'] = nb * B * g.T / (time.perf_counter() - t1)   # transfers under the neighbours' compute
         traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
 

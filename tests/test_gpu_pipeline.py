@@ -261,3 +261,23 @@ def test_nmf_file_groups_on_streams_are_bitwise_the_single_stream_result():
         assert np.array_equal(eg.separate(xs), y1)
     with pytest.raises(ValueError):
         engine(32000, nmf_groups=5, **kw)
+
+
+def test_separate_batches_overlaps_transfers_and_matches_separate():
+    """The pipelined host-to-host path (pinned staging, copy streams) returns, batch by batch and in order, exactly what
+    ``separate`` returns; the engine is usable as before afterwards; bad input surfaces as the reference's error."""
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    e = engine(32000, dictionarySize=64, numIterations=8, batch=4)
+    batches = [synthetic_batch(400 + 4 * i, 4, numSamples=32000) for i in range(5)]
+    expect = [e.separate(b) for b in batches]
+    got = list(e.separate_batches(iter(batches)))
+    assert len(got) == 5
+    for a, b in zip(got, expect):
+        assert np.array_equal(a, b)
+    assert np.array_equal(e.separate(batches[2]), expect[2])
+    assert list(e.separate_batches([])) == []
+    bad = batches[1].copy()
+    bad[0, 0, 5] = np.nan
+    with pytest.raises(ValueError):
+        list(e.separate_batches([batches[0], bad]))
+    assert np.array_equal(e.separate(batches[0]), expect[0])
