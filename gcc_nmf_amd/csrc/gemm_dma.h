@@ -10,8 +10,11 @@
 // (q, e), q = 0..1, e = 0..3, multiplies k = 8q + e in lanes 0-31 with k = 8q + 4 + e in lanes 32-63; A and B use the same
 // assignment, so only the (irrelevant, exact-f32) summation order inside the tile changes.
 //
-// The lazy H row scale of K1 is applied to the B fragments after the LDS read (fl(H*s) exactly as before).
-// Epilogues, the VALU tail row and the row sums are those of gemm_mfma.h.
+// The lazy H row scale of K1 is applied to the B fragments after the LDS read (fl(H*s), as the register-staged kernel does
+// while staging).  Full tiles take the lean epilogues below, ragged ones the generic epilogues of gemm_mfma.h.
+//
+// Measurement tooling lives here too: gccnmf_debug_set_trace (per-workgroup timeline, scripts/ktrace.py) and the
+// GEMM_DMA_PROBE build (per-phase cycle counts of the k-tile, scripts/ktrace.py --probe).
 #pragma once
 #include <type_traits>
 #include "gemm_mfma.h"
@@ -27,7 +30,7 @@ __device__ __forceinline__ void gemm_dma16(const float* src, float* lds_wave_bas
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 2) & 3; }
 
 // MFMA fragment reads as inline asm: the compiler neither sees them as LDS reads (so it does not drain the LDS-DMA queue
-// in front of them) nor waits for them -- every use is preceded by a hand-placed s_waitcnt lgkmcnt + sched_barrier.
+// in front of them) nor waits for them -- every use is preceded by gemm_wait_lds() + gemm_tie() on the destination.
 typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ gemm_f32x4 gemm_lds_read_b128(unsigned byte_addr) {
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const bool tail_dma = TAIL && do_tail && wave == 0 && lane < 4, scale_dma = SCALE && bscale && wave == 1 && lane < 4;
 
     // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
-    // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop, one piece per two MFMAs.)
+    // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
     auto dma_piece = [&](const int piece, const int kt, const int buf) {
         float* sb = smem + buf * SBUF;
         if (piece < 8) {
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     // Fragment registers.  Group 0 = first k half (q = 0) of a tile + its row-scale chunk; group 1 = second half + the
     // operands of the VALU side work (tail row, row sums).  All LDS reads are inline asm (the compiler would drain the
     // LDS-DMA queue, s_waitcnt vmcnt(0), in front of any ds_read it can see after a global_load_lds); every group is
-    // made visible by gemm_wait_*(): an `s_waitcnt lgkmcnt(0)` that "redefines" the registers, so no use can move above it.
+    // made visible by wait_group0/1(): gemm_wait_lds() + gemm_tie() of every destination, so no use can move above the wait.
     const gemm_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     GemmFrag<A_KC, TM, BM> a0, a1;
     GemmFrag<B_KC, 2, BN> b0, b1;
