@@ -100,7 +100,13 @@ class GCCNMFEngine(object):
         # Measured (64 files, K = 1024): 1 group 287.0 ms per step, 2 groups 278-280 ms; 4 groups 308 ms with the default 4
         # hardware queues (two groups end up sharing one and serialise) and 277 ms with GPU_MAX_HW_QUEUES=8 -- so 2.
         if nmf_groups is None:
-            nmf_groups = 2 if (self.batch >= 32 and self.batch % 2 == 0) else 1
+            # two groups only when each half alone still makes the library's launch-size decisions exactly as the whole
+            # batch would (>= 256 throughput tiles per GEMM launch, >= 256 atom tiles for the fused W update): the same
+            # kernels run either way and the outputs are bit-identical
+            half = self.batch // 2
+            tiles_wh = -(-(2 * num_frames(self.n_samples, self.n_fft, self.hop)) // 64)
+            atoms = -(-int(dictionarySize) // 64)
+            nmf_groups = 2 if (self.batch % 2 == 0 and half >= 16 and half * tiles_wh >= 256 and half * atoms >= 256) else 1
         if nmf_groups < 1 or self.batch % nmf_groups:
             raise ValueError('nmf_groups must divide the batch')
         self.nmf_groups = int(nmf_groups)

@@ -253,9 +253,11 @@ def test_nmf_file_groups_on_streams_are_bitwise_the_single_stream_result():
     kw = dict(dictionarySize=128, numIterations=10, batch=32)
     e1 = engine(32000, nmf_groups=1, **kw)
     y1 = e1.separate(xs)
-    for groups in (None, 4):
+    assert engine(32000, **kw).nmf_groups == 1          # K = 128: a half batch would no longer fuse / fill the chip like the whole
+    assert engine(160000, dictionarySize=1024, numIterations=1, batch=32).nmf_groups == 2
+    for groups in (2, 4):
         eg = engine(32000, nmf_groups=groups, **kw)
-        assert eg.nmf_groups == (2 if groups is None else groups)             # default: two groups from 32 files up
+        assert eg.nmf_groups == groups
         yg = eg.separate(xs)
         assert np.array_equal(yg, y1) and torch.equal(eg.W, e1.W) and torch.equal(eg.H, e1.H)
         assert np.array_equal(eg.separate(xs), y1)
