@@ -60,6 +60,27 @@ __device__ __forceinline__ void gemm_wait_lds() { asm volatile("s_waitcnt lgkmcn
 template <typename T>
 __device__ __forceinline__ void gemm_tie(T& v) { asm volatile("" : "+v"(v)); }
 
+// Split workgroup barrier on an LDS counter (gfx950 has only the monolithic s_barrier): a wave ARRIVES (one atomic add, no
+// return, exec narrowed to one lane inside the asm) as soon as its own part of the hand-over is done, and WAITS -- later
+// in its instruction stream -- until all arrivals of that round are in.  Both are single asm statements (the poll loop
+// included), so the compiler sees no control flow and its register allocation of the main loop is untouched.
+__device__ __forceinline__ void gemm_barrier_arrive(unsigned counter_byte_addr) {
+    unsigned long long saved;
+    const unsigned one = 1u;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(counter_byte_addr), "v"(one)
+                 : "memory");
+}
+__device__ __forceinline__ void gemm_barrier_wait(unsigned counter_byte_addr, unsigned target) {
+    unsigned seen, seen_s;
+    asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_ge_u32 %1, %3\n\t"
+                 "s_cbranch_scc1 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(seen), "=&s"(seen_s)
+                 : "v"(counter_byte_addr), "s"(target)
+                 : "memory", "scc");
+}
+
 // MFMA fragments of one k half (4 consecutive MFMA steps e = 0..3) for NT 32-row tiles; every address is ONE base VGPR +
 // an immediate offset.
 template <bool KC, int NT, int ROWS>
@@ -71,7 +92,7 @@ struct GemmFrag<true, NT, ROWS> {
     __device__ __forceinline__ void read(unsigned base) {
         v[0] = gemm_lds_read_b128<0 * 2048>(base);
         v[1] = gemm_lds_read_b128<1 * 2048>(base);
-        if (NT == 4) {
+        if constexpr (NT == 4) {
             v[2] = gemm_lds_read_b128<2 * 2048>(base);
             v[3] = gemm_lds_read_b128<3 * 2048>(base);
         }
@@ -95,7 +116,7 @@ struct GemmFrag<false, NT, ROWS> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             v[e][0] = gemm_lds_read2_b32<0, 32>(base + 4 * e * ROWS);
-            if (NT == 4) v[e][1] = gemm_lds_read2_b32<64, 96>(base + 4 * e * ROWS);
+            if constexpr (NT == 4) v[e][1] = gemm_lds_read2_b32<64, 96>(base + 4 * e * ROWS);
         }
     }
     __device__ __forceinline__ void tie() {
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);   // K1 (R = V / (W.(s*H))) carries a lazy row scale on its B operand
     __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
     __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * BM : 4];   // lean epilogue row factors
+    __shared__ unsigned s_arrivals;                  // split barrier of the main loop: 4 arrivals per k-tile
 
     const int tiles = p.tiles_m * p.tiles_n;
     int file, tile;
@@ -390,8 +412,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
     const int nkt = (p.Kd + BK - 1) / BK;
-    const float* __restrict__ tailA = A + (long)p.tail_row * p.lda + 4 * (lane & 3);
-    const bool tail_dma = TAIL && do_tail && wave == 0 && lane < 4, scale_dma = SCALE && bscale && wave == 1 && lane < 4;
+    // the two 64-byte side chunks (tail row of A, row scale of B) sit next to each other behind the B tile: ONE piece of wave 0,
+    // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk
+    const float* __restrict__ side_src = (lane < 4) ? A + (long)p.tail_row * p.lda + 4 * lane : (bscale ? bscale + 4 * (lane - 4) : A);
+    const bool side_dma = wave == 0 && ((TAIL && do_tail && lane < 4) || (SCALE && bscale != nullptr && lane >= 4 && lane < 8));
 
     // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
     // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
@@ -402,11 +426,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         } else if (piece == 8) {
             gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb) + offB, sb + SA + wave * 256);
         } else {
-            if (TAIL) {
-                if (tail_dma) gemm_dma16(tailA + kt * BK, sb + SA + SB);
-            }
-            if (SCALE) {
-                if (scale_dma) gemm_dma16(bscale + kt * BK + 4 * lane, sb + SA + SB + BK);
+            if (TAIL || SCALE) {
+                if (side_dma) gemm_dma16(side_src + kt * BK, sb + SA + SB);
             }
         }
     };
@@ -431,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     float tbx = 0.f, tby = 0.f, tbz = 0.f, tbw = 0.f;
 
     const unsigned lds0 = (unsigned)(size_t)(gemm_lds_ptr)smem;
+    const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)&s_arrivals;
     // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
     const unsigned oA0 = A_KC ? 4 * (arow * 16 + 4 * ((0 + hh) ^ gemm_swz(arow))) : 4 * (4 * (0 + hh) * BM + arow);
     const unsigned oA1 = A_KC ? 4 * (arow * 16 + 4 * ((2 + hh) ^ gemm_swz(arow))) : 4 * (4 * (2 + hh) * BM + arow);
@@ -523,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             }
         }
     }
+    if (tid == 0) s_arrivals = 0;
     // prologue: tile 0 -> buffer 0, group 0 of tile 0 into registers
 #pragma unroll
     for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
@@ -547,8 +570,12 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     // phase of the k-tile, summed over the main loop, per wave
     unsigned long long probe[7] = {0, 0, 0, 0, 0, 0, 0};
 #define GEMM_PROBE(i_) const unsigned long long pt##i_ = __builtin_amdgcn_s_memtime()
+#define GEMM_PROBE_DECL(i_) unsigned long long pt##i_ = 0
+#define GEMM_PROBE_SET(i_) pt##i_ = __builtin_amdgcn_s_memtime()
 #else
 #define GEMM_PROBE(i_)
+#define GEMM_PROBE_DECL(i_)
+#define GEMM_PROBE_SET(i_)
 #endif
     auto step = [&](auto cur_c, const int kt) {
         constexpr int CUR = decltype(cur_c)::value;
@@ -586,25 +613,37 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         GEMM_PROBE(1);
         wait_group1();
         GEMM_PROBE(2);
-        if (wave_active) {
+        GEMM_PROBE_DECL(3);
+        GEMM_PROBE_DECL(4);
+        GEMM_PROBE_DECL(5);
+#ifndef GEMM_DMA_ARRIVE_E
+#define GEMM_DMA_ARRIVE_E 1        // MFMA groups (8 each) of the second k half issued before the arrival ...
+#define GEMM_DMA_WAIT_E 3          // ... and before the wait + the reads of the next tile's group 0
+#endif
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 4; ++e) {
+            if (e == GEMM_DMA_ARRIVE_E) {
+                // this wave's part of the hand-over: its pieces of tile t+1 have landed, its last reads of tile t are done
+                __builtin_amdgcn_sched_barrier(0);
+                GEMM_PROBE_SET(3);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                gemm_barrier_arrive(arrivals_addr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (e == GEMM_DMA_WAIT_E) {
+                // every wave has arrived: tile t+1 is complete in LDS, and nobody reads tile t any more (its buffer is the
+                // target of the next step's pieces)
+                __builtin_amdgcn_sched_barrier(0);
+                GEMM_PROBE_SET(4);
+                gemm_barrier_wait(arrivals_addr, 4u * (unsigned)(kt + 1));
+                GEMM_PROBE_SET(5);
+                read_group0(ldsN);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (wave_active) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m) mma(a1, b1, e, m);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_PROBE(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GEMM_PROBE(4);
-        __syncthreads();
-        GEMM_PROBE(5);
-        read_group0(ldsN);
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave_active) {
-#pragma unroll
-            for (int e = 2; e < 4; ++e)
-#pragma unroll
-                for (int m = 0; m < TM; ++m) mma(a1, b1, e, m);
+            }
         }
         if (TAIL) {
             if (do_tail) {
@@ -625,10 +664,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         const unsigned long long pt7 = __builtin_amdgcn_s_memtime();
         probe[0] += pt1 - pt0;      // group-1 read issue, 32 MFMAs, LDS-DMA pieces
         probe[1] += pt2 - pt1;      // wait group 1
-        probe[2] += pt3 - pt2;      // 16 MFMAs
-        probe[3] += pt4 - pt3;      // wait LDS-DMA
-        probe[4] += pt5 - pt4;      // barrier
-        probe[5] += pt6 - pt5;      // group-0 read issue, 16 MFMAs, side FMAs
+        probe[2] += pt3 - pt2;      // MFMAs of the second half before the arrival
+        probe[3] += pt4 - pt3;      // wait LDS-DMA, arrive, MFMAs up to the wait
+        probe[4] += pt5 - pt4;      // split-barrier wait
+        probe[5] += pt6 - pt5;      // group-0 read issue, remaining MFMAs, side FMAs
         probe[6] += pt7 - pt6;      // wait group 0
         __builtin_amdgcn_sched_barrier(0);
 #endif

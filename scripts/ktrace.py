@@ -58,7 +58,7 @@ def main():
     if a.probe:
         pr = t_all[grid:5 * grid, :7].reshape(grid, 4, 7).astype(np.float64)
         nkt = {1: K // 16, 3: K // 16, 2: (F - 1) // 16, 4: g.Np // 16}[a.stage]
-        names = ['G1 issue + 32 MFMA + DMA', 'wait G1', '16 MFMA', 'wait DMA', 'barrier', 'G0 issue + 16 MFMA', 'wait G0']
+        names = ['G1 issue + 32 MFMA + DMA', 'wait G1', '8 MFMA', 'wait DMA, arrive, 16 MFMA', 'split-barrier wait', 'G0 issue + 8 MFMA', 'wait G0']
         start = (t[:, 0] - t[:, 0].min()) / 100.0
         loop = (t[:, 2] - t[:, 1]) / 100.0
         first = start < 5
@@ -68,8 +68,9 @@ def main():
         for name, sel in groups.items():
             m = pr[sel].mean(axis=(0, 1)) / nkt
             print('%s: %d workgroups, main loop %.0f us, cycles per k-tile %.0f (solo MFMA time 4096)' % (name, sel.sum(), loop[sel].mean(), m.sum()))
-            for n, v in zip(names, m):
-                print('     %-28s %7.0f' % (n, v))
+            mw = pr[sel].mean(axis=0) / nkt                      # per wave
+            for i, (n, v) in enumerate(zip(names, m)):
+                print('     %-28s %7.0f   per wave: %s' % (n, v, '  '.join('%6.0f' % x for x in mw[:, i])))
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     us = (t[:, :4] - t0) / 100.0                     # 100 MHz -> microseconds
