@@ -102,11 +102,14 @@ __global__ __launch_bounds__(256) void nmf_prepare_kernel(const float* __restric
 // grid = batch * Kp/AT, 256 threads = AT atoms x 256/AT row phases; W and U are read twice (L2-resident) instead of
 // keeping F*AT/256 values per thread in registers.  AT = 64 for big batches (256-byte row segments); AT = 16 when the
 // launch would otherwise be a handful of workgroups (single file: 16 -> 64 workgroups, 4x shorter row loops).
+// nsplit > 1 (single-file split-K, below): U and rowsumH arrive as nsplit partial sums, sSplitU / sSplitR floats apart,
+// and are added in ascending split order wherever they are read.
 template <int AT>
 __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W, const float* __restrict__ U,
                                                            const float* __restrict__ rowsumH, float* __restrict__ colsumW,
                                                            float* __restrict__ hscale, int F, int Fp, int K, int Kp,
-                                                           long sW, long sU, long sVec, long sRowsum) {
+                                                           long sW, long sU, long sVec, long sRowsum, int nsplit, long sSplitU,
+                                                           long sSplitR) {
     constexpr int PH = 256 / AT;
     __shared__ float red[256];
     __shared__ float s_norm[AT];
@@ -117,11 +120,20 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
     const bool valid = k < K;          // padded atoms stay exactly zero
     float* Wb = W + b * sW;
     const float* Ub = U + b * sU;
-    const float rs = valid ? rowsumH[b * sRowsum + k] : 1.f;
+    float rs = 1.f;
+    if (valid) {
+        rs = rowsumH[b * sRowsum + k];
+        for (int sp = 1; sp < nsplit; ++sp) rs += rowsumH[b * sRowsum + sp * sSplitR + k];
+    }
+    auto u_at = [&](long i) {
+        float u = Ub[i];
+        for (int sp = 1; sp < nsplit; ++sp) u += Ub[sp * sSplitU + i];
+        return u;
+    };
     float ss = 0.f;
     if (valid)
         for (int f = q; f < F; f += PH) {
-            const float wt = Wb[(long)f * Kp + k] * (Ub[(long)f * Kp + k] / rs);
+            const float wt = Wb[(long)f * Kp + k] * (u_at((long)f * Kp + k) / rs);
             ss = fmaf(wt, wt, ss);
         }
     red[threadIdx.x] = ss;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
     if (valid)
         for (int f = q; f < F; f += PH) {
             const long i = (long)f * Kp + k;
-            const float wn = (Wb[i] * (Ub[i] / rs)) / norm;
+            const float wn = (Wb[i] * (u_at(i) / rs)) / norm;
             Wb[i] = wn;
             cs += wn;
         }
@@ -154,13 +166,14 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
 }
 
 static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,
-                           int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s) {
+                           int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s, int nsplit = 1,
+                           long sSplitU = 0, long sSplitR = 0) {
     if ((long)batch * (Kp / 64) >= 256) {
         hipLaunchKernelGGL(nmf_update_w_kernel<64>, dim3(batch * (Kp / 64)), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, Fp, K,
-                           Kp, sW, sU, sVec, sRowsum);
+                           Kp, sW, sU, sVec, sRowsum, nsplit, sSplitU, sSplitR);
     } else {
         hipLaunchKernelGGL(nmf_update_w_kernel<16>, dim3(batch * (Kp / 16)), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, Fp, K,
-                           Kp, sW, sU, sVec, sRowsum);
+                           Kp, sW, sU, sVec, sRowsum, nsplit, sSplitU, sSplitR);
     }
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
@@ -327,12 +340,76 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, false>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------
+// One file alone (BASELINE config 2 as a single mixture): split-K
+// ------------------------------------------------------------------------------------------
+// A launch over ONE file has 64-80 small-batch tiles for 256 CUs, each a 64..78-step dependent chain: latency-bound.  The two
+// long reductions are therefore cut into GCCNMF_SPLITS equal parts that run as independent "files" of the batched kernel
+// (operand base + part * length, partial outputs side by side): W.H over the atoms, R.H^T over the columns.  The parts
+// are added in ascending order by the consumer -- nmf_div_partials_kernel (R = V / sum) and nmf_update_w_kernel -- so the
+// result does not depend on scheduling.  Zero padding makes the parts equal: Kp and Np are multiples of 64.
+#define GCCNMF_SPLITS 4
+
+// R[f][n] = V[f][n] / (P_0 + P_1 + ... )[f][n] on the valid F x N region only (R's padding must stay zero)
+__global__ __launch_bounds__(256) void nmf_div_partials_kernel(const float* __restrict__ V, const float* __restrict__ P, long sP,
+                                                               int nsplit, int F, int N, int Np, float* __restrict__ R) {
+    const int n = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (n >= N || f >= F) return;
+    const long i = (long)f * Np + n;
+    float d = P[i];
+    for (int sp = 1; sp < nsplit; ++sp) d += P[sp * sP + i];
+    R[i] = V[i] / d;
+}
+
+// reduction length (padded) worth cutting: at least 8 k-tiles per part
+static bool single_file_split(const NmfGeom& g, int batch, int reduction) {
+    return batch == 1 && gccnmf_tune_tile_policy != 1 && g.Fm > 128 && reduction >= GCCNMF_SPLITS * 128;
+}
+
+// P_part = W[:, part] . (hscale * H)[part, :]   (EPI_STORE incl. the VALU tail row), then R = V / sum_part P_part
+static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W, const float* H, const float* hscale, float* P, float* R,
+                               hipStream_t s) {
+    const int len = g.Kp / GCCNMF_SPLITS;                    // atoms per part (multiple of 16)
+    GemmArgs a = {};
+    a.A = W; a.sA = len; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = (long)len * g.Np; a.ldb = g.Np; a.b_clamp = g.Np - 4;
+    a.M = g.Fm; a.N = g.N; a.Kd = len;
+    a.batch = GCCNMF_SPLITS; a.xcd_affine = 0;
+    a.bscale = hscale; a.s_bscale = len;
+    a.tail_row = g.F - 1;
+    a.C = P; a.sC = g.sV; a.ldc = g.Np;
+    int rc = g.tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false, 1>(a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nmf_div_partials_kernel, dim3(gccnmf_ceil_div(g.N, 256), g.F), dim3(256), 0, s, V, P, g.sV, GCCNMF_SPLITS, g.F, g.N,
+                       g.Np, R);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// U_part = R[:, part] . H[:, part]^T, rowsum_part = sum_{n in part} H   (consumed by nmf_update_w_kernel with nsplit parts)
+static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, float* Upart, float* rowsum_part, hipStream_t s) {
+    const int len = g.Np / GCCNMF_SPLITS;                    // columns per part (multiple of 16; beyond N both operands are zero)
+    GemmArgs a = {};
+    a.A = R; a.sA = len; a.lda = g.Np; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = len; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
+    a.M = g.Fm; a.N = g.K; a.Kd = len;
+    a.batch = GCCNMF_SPLITS; a.xcd_affine = 0;
+    a.tail_row = g.F - 1;
+    a.rowsumB = rowsum_part; a.s_rowsumB = g.Kp;
+    a.C = Upart; a.sC = g.sU; a.ldc = g.Kp;
+    return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
+}
+
 extern "C" {
 
+// R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
+// GCCNMF_SPLITS x max(Fp*Np, Fp*Kp) (W.H parts and R.H^T parts use the same memory at different stages) + GCCNMF_SPLITS x Kp
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
-    return (long)batch * (g.sV + g.sU + 3L * g.Kp);
+    long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
+    if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
+    return n;
 }
 
 // One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
@@ -344,6 +421,9 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* colsumW = U + (long)batch * g.sU;
     float* rowsumH = colsumW + (long)batch * g.Kp;
     float* hscale = rowsumH + (long)batch * g.Kp;
+    float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
+    float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
+    const bool split_wh = single_file_split(g, batch, g.Kp), split_rht = single_file_split(g, batch, g.Np);
     const int xcd = (flags & 1) ? 0 : 1;
     const int vec_grid = batch * (g.Kp / 64);
     switch (stage) {
@@ -352,13 +432,21 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             if (hipMemsetAsync(R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
             hipLaunchKernelGGL(nmf_prepare_kernel, dim3(vec_grid), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
             break;
-        case 1: return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
+        case 1:
+            if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, s);
+            return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
         case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
-        case 3: return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
+        case 3:
+            if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, s);
+            return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
         case 4:
+            if (split_rht) return launch_rht_split(g, R, H, parts, rowsum_parts, s);
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
             return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
         case 5:
+            if (split_rht)
+                return launch_update_w(W, parts, rowsum_parts, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch,
+                                       s, GCCNMF_SPLITS, g.sU, (long)g.Kp);
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
             return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s);
         case 6:

@@ -138,7 +138,8 @@ class GCCNMFEngine(object):
             self.CC = z(B, 2, g.Fp, g.Tp)
             self.W = z(B, g.Fp, g.Kp)
             self.H = z(B, g.Kp, g.Np)
-            self.ws_nmf = z(self.lib.gccnmf_klnmf_workspace_floats(F, g.N, g.K, B))          # = nmf_groups equal group workspaces
+            # nmf_groups equal group workspaces (for one group == the whole-batch workspace)
+            self.ws_nmf = z(self.nmf_groups * self.lib.gccnmf_klnmf_workspace_floats(F, g.N, g.K, B // self.nmf_groups))
             self.nmf_streams = [torch.cuda.Stream(device=dev) for _ in range(self.nmf_groups)] if self.nmf_groups > 1 else []
             self.ang = z(B, g.Dp, g.Tp)
             self.mean_ang = torch.zeros((B, g.Dp), dtype=torch.float64, device=dev)

@@ -224,7 +224,9 @@ def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha, tile_policy):
 
 
 def test_klnmf_batch_is_file_independent(hip):
-    """A file's result does not depend on the batch it rides in (XCD-affine map for batch >= 8 included)."""
+    """A file's result does not depend on the batch it rides in (XCD-affine map for batch >= 8 included): bit for bit between
+    batches of two or more; a file processed ALONE takes the split-K latency path (reductions cut in four parts, added in a
+    fixed order) and agrees to summation-order accuracy."""
     lib = hip.lib()
     F, T, K, B = 513, 30, 128, 9
     N = 2 * T
@@ -234,7 +236,7 @@ def test_klnmf_batch_is_file_independent(hip):
     V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
     W0, H0 = klnmf_initial_factors(F, N, K)
     outs = []
-    for files in ([0], [8], list(range(B))):
+    for files in ([0, 3], [5, 8], list(range(B)), [8]):
         b = len(files)
         dV = padded(V[files], (b, g.Fp, g.Np), 'cuda')
         dW = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
@@ -243,7 +245,9 @@ def test_klnmf_batch_is_file_independent(hip):
         assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, b, 5, 0.0, 1e-16, 0, stream()) == 0
         outs.append((dW.cpu().numpy(), dH.cpu().numpy()))
     assert np.array_equal(outs[0][0][0], outs[2][0][0]) and np.array_equal(outs[0][1][0], outs[2][1][0])
-    assert np.array_equal(outs[1][0][0], outs[2][0][8]) and np.array_equal(outs[1][1][0], outs[2][1][8])
+    assert np.array_equal(outs[0][0][1], outs[2][0][3]) and np.array_equal(outs[0][1][1], outs[2][1][3])
+    assert np.array_equal(outs[1][0][1], outs[2][0][8]) and np.array_equal(outs[1][1][1], outs[2][1][8])
+    assert rel(outs[3][0][0], outs[2][0][8]) < 2e-6 and rel(outs[3][1][0], outs[2][1][8]) < 2e-6        # alone: split-K
     # padding stayed zero
     Wp, Hp = outs[2]
     assert not Wp[:, F:, :].any() and not Wp[:, :, K:].any() and not Hp[:, K:, :].any() and not Hp[:, :, N:].any()

@@ -155,8 +155,8 @@ def test_zero_magnitude_bins_do_not_poison_the_batch():
         e.separate(np.stack([good, bad]))
     assert np.isfinite(e.get_angular()[0]).all() and np.isfinite(e.get_C()).all()
     y0 = e.y[0].cpu().numpy()
-    e1 = engine(n, dictionarySize=32, numIterations=5, batch=1)
-    assert np.array_equal(e1.separate(good)[0], y0)
+    e2 = engine(n, dictionarySize=32, numIterations=5, batch=2)                # the clean file next to another clean file
+    assert np.array_equal(e2.separate(np.stack([good, good]))[1], y0)
 
 
 def test_benchmark_shape_properties():
@@ -164,9 +164,9 @@ def test_benchmark_shape_properties():
       - masks partition the coefficients: sum_i S[i,c] == (W.H_c) * X_c/|X_c|
       - KL divergence D(V || W.H) after 30 iterations is below the value after 5 (multiplicative updates descend)
       - unit-L2 atoms, non-negative factors, untouched zero padding
-      - every file of the batch equals its own single-file run: bit for bit when both runs use the same GEMM tile (the
-        result does not depend on the batch position or size), and to 1e-6 of the signal RMS under the automatic tile
-        policy (the small-batch tile sums each 16-deep k-tile in a different order than the LDS-DMA throughput tile)."""
+      - every file of the batch equals its own run in another batch: bit for bit when both runs use the same GEMM tile (the
+        result does not depend on the batch position or size), and to 1e-6 of the signal RMS for the file ALONE (split-K
+        latency path, and the small-batch tile sums each 16-deep k-tile in a different order than the LDS-DMA tile)."""
     from gcc_nmf_amd.synthetic import synthetic_batch
     xs = synthetic_batch(100, 8)
     e = engine(160000, dictionarySize=1024, numIterations=30, batch=8)
@@ -205,14 +205,18 @@ def test_benchmark_shape_properties():
     assert np.sqrt(np.mean((y1[0] - y[5]) ** 2)) < 1e-6 * np.sqrt(np.mean(y[5] ** 2))
     from gcc_nmf_amd import _hip
     lib = _hip.lib()
+    e2 = engine(160000, dictionarySize=1024, numIterations=30, batch=2)
     for policy in (1, 2):                 # same GEMM tile for both batch sizes -> bit-identical
         assert lib.gccnmf_set_tuning(2, policy) == 0
         try:
             y8 = e.separate(xs)
+            y2 = e2.separate(xs[4:6])
             y1 = e1.separate(xs[5])
         finally:
             lib.gccnmf_set_tuning(2, 0)
-        assert np.array_equal(y1[0], y8[5]), policy
+        assert np.array_equal(y2[1], y8[5]), policy
+        if policy == 1:                   # forcing the throughput tile also switches the single-file split-K off
+            assert np.array_equal(y1[0], y8[5])
 
 
 def test_pcm16_ingest_and_egress(dev1, tmp_path):
