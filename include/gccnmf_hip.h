@@ -78,7 +78,10 @@ int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scra
  * W, H (:70-73) are drawn on the host and passed in.  W and H are updated in place.
  *   V [batch][Fp][Np], W [batch][Fp][Kp], H [batch][Kp][Np] with Np = round_up(N,64); N = 2T on the
  *   GCC-NMF path but any N >= 1 is accepted (performKLNMF is also called on arbitrary V).
- *   workspace: gccnmf_klnmf_workspace_floats(...) floats of scratch (R, R.H^T, K-vectors). */
+ *   workspace: gccnmf_klnmf_workspace_floats(...) floats of scratch (R, R.H^T, K-vectors; for batch == 1 also the partial
+ *   products of the split-K latency path).  Always size it with the batch of the call it is used with.
+ *   batch >= 2: a file's result is bit-identical whatever batch it rides in (for equal launch-size decisions); batch == 1
+ *   cuts the two long reductions in four parts added in a fixed order (deterministic, summation-order accuracy). */
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch);
 int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
                  int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
