@@ -26,6 +26,15 @@ __device__ __forceinline__ void gemm_dma16(const float* src, float* lds_wave_bas
     // lane l lands at lds_wave_base + 16*l bytes; lds_wave_base must be wave-uniform
     __builtin_amdgcn_global_load_lds((gemm_glb_ptr)src, (gemm_lds_ptr)lds_wave_base, 16, 0, 0);
 }
+// The same with the address split into a wave-uniform base (SGPR pair) and an unsigned 32-bit per-lane byte offset, as inline
+// asm: hipcc does not select the `saddr + voffset` form for the builtin (it adds base + offset on the VALU, per piece, and
+// keeps the offsets as 64-bit pairs).  M0 = LDS byte address of the piece (wave-uniform).
+__device__ __forceinline__ void gemm_dma16(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_wave_byte_addr)
+                 : "memory");     // (M0 is written; every other user of M0 here -- the builtin form above -- sets it right before its use)
+}
 
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 2) & 3; }
 
@@ -382,24 +391,24 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
 
     // per-lane source offsets (elements) of this wave's DMA pieces: 8 of A, 1 of B
-    int offA[8], offB;
+    unsigned offA[8], offB;                                            // bytes from the (wave-uniform) k-tile origin
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int piece = wave * 8 + i;                                // 1 KB pieces of the A tile
         if (A_KC) {
             const int row = piece * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(piece * 16 + (lane >> 2));
-            offA[i] = min(row0 + row, p.a_clamp) * p.lda + 4 * c;
+            offA[i] = 4u * (unsigned)(min(row0 + row, p.a_clamp) * p.lda + 4 * c);
         } else {
             const int kk = piece >> 1, col = (piece & 1) * 256 + lane * 4;
-            offA[i] = kk * p.lda + min(row0 + col, p.a_clamp);
+            offA[i] = 4u * (unsigned)(kk * p.lda + min(row0 + col, p.a_clamp));
         }
     }
     if (B_KC) {
         const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(row);
-        offB = min(col0 + row, p.b_clamp) * p.ldb + 4 * c;
+        offB = 4u * (unsigned)(min(col0 + row, p.b_clamp) * p.ldb + 4 * c);
     } else {
         const int kk = wave * 4 + (lane >> 4), col = (lane & 15) * 4;
-        offB = kk * p.ldb + min(col0 + col, p.b_clamp);
+        offB = 4u * (unsigned)(kk * p.ldb + min(col0 + col, p.b_clamp));
     }
 
     f32x16 acc[TM][2];
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
     const int nkt = (p.Kd + BK - 1) / BK;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(gemm_lds_ptr)smem);
     // the two 64-byte side chunks (tail row of A, row scale of B) sit next to each other behind the B tile: ONE piece of wave 0,
     // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk
     const float* __restrict__ side_src = (lane < 4) ? A + (long)p.tail_row * p.lda + 4 * lane : (bscale ? bscale + 4 * (lane - 4) : A);
@@ -422,9 +432,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     auto dma_piece = [&](const int piece, const int kt, const int buf) {
         float* sb = smem + buf * SBUF;
         if (piece < 8) {
-            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda) + offA[piece], sb + (wave * 8 + piece) * 256);
+            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece], lds0 + 4 * (buf * SBUF + (wave * 8 + piece) * 256));
         } else if (piece == 8) {
-            gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb) + offB, sb + SA + wave * 256);
+            gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb), offB, lds0 + 4 * (buf * SBUF + SA + wave * 256));
         } else {
             if (TAIL || SCALE) {
                 if (side_dma) gemm_dma16(side_src + kt * BK, sb + SA + SB);
@@ -451,7 +461,6 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     gemm_f32x4 sc0 = zero4, sc1 = zero4, t4 = zero4, tb4 = zero4, ts4 = zero4, rs4 = zero4;
     float tbx = 0.f, tby = 0.f, tbz = 0.f, tbw = 0.f;
 
-    const unsigned lds0 = (unsigned)(size_t)(gemm_lds_ptr)smem;
     const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)&s_arrivals;
     // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
     const unsigned oA0 = A_KC ? 4 * (arow * 16 + 4 * ((0 + hh) ^ gemm_swz(arow))) : 4 * (4 * (0 + hh) * BM + arow);
