@@ -36,6 +36,17 @@ __device__ __forceinline__ void gemm_dma16(const float* wave_uniform_base, unsig
                  : "memory");     // (M0 is written; every other user of M0 here -- the builtin form above -- sets it right before its use)
 }
 
+// A piece fetched by a few lanes only (`mask`, compile-time): exec is narrowed and restored inside the asm, so the main loop
+// carries no v_cmp / s_and_saveexec for it.
+template <unsigned MASK>
+__device__ __forceinline__ void gemm_dma16_lanes(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_wave_byte_addr), "n"(MASK)
+                 : "memory");
+}
+
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 2) & 3; }
 
 // MFMA fragment reads as inline asm: the compiler neither sees them as LDS reads (so it does not drain the LDS-DMA queue
@@ -424,20 +435,24 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(gemm_lds_ptr)smem);
     // the two 64-byte side chunks (tail row of A, row scale of B) sit next to each other behind the B tile: ONE piece of wave 0,
     // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk
-    const float* __restrict__ side_src = (lane < 4) ? A + (long)p.tail_row * p.lda + 4 * lane : (bscale ? bscale + 4 * (lane - 4) : A);
-    const bool side_dma = wave == 0 && ((TAIL && do_tail && lane < 4) || (SCALE && bscale != nullptr && lane >= 4 && lane < 8));
+    // fetched by wave 0: lanes 0-3 the tail chunk, lanes 4-7 the scale chunk -- both land at (tail chunk) + 16 * lane
+    const float* __restrict__ tail_src = A + (long)p.tail_row * p.lda;
+    const unsigned side_off = 16u * (unsigned)(lane & 3);
 
     // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
     // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
     auto dma_piece = [&](const int piece, const int kt, const int buf) {
-        float* sb = smem + buf * SBUF;
         if (piece < 8) {
             gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece], lds0 + 4 * (buf * SBUF + (wave * 8 + piece) * 256));
         } else if (piece == 8) {
             gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb), offB, lds0 + 4 * (buf * SBUF + SA + wave * 256));
         } else {
             if (TAIL || SCALE) {
-                if (side_dma) gemm_dma16(side_src + kt * BK, sb + SA + SB);
+                if (wave == 0) {                                   // wave-uniform: scalar branches only
+                    const unsigned dst = lds0 + 4 * (buf * SBUF + SA + SB);
+                    if (TAIL && do_tail) gemm_dma16_lanes<0x0fu>(tail_src + kt * BK, side_off, dst);
+                    if (SCALE && bscale != nullptr) gemm_dma16_lanes<0xf0u>(bscale + kt * BK, side_off, dst);
+                }
             }
         }
     };
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         b0.tie();
         if (SCALE) {
             gemm_tie(sc0);
-            if (bscale) b0.scale(sc0);                             // lazy H row scale: fl(H * s), as the staged form does
+            b0.scale(sc0);                                         // lazy H row scale: fl(H * s), as the staged form does (1.0 without one)
         }
     };
     auto wait_group1 = [&]() {
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         b1.tie();
         if (SCALE) {
             gemm_tie(sc1);
-            if (bscale) b1.scale(sc1);
+            b1.scale(sc1);
         }
         if (TAIL) {
             gemm_tie(t4);
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 tb4 = gemm_f32x4{tbx, tby, tbz, tbw};
                 if (SCALE) {
                     gemm_tie(ts4);
-                    if (bscale) tb4 *= ts4;
+                    tb4 *= ts4;
                 }
             }
         }
@@ -555,6 +570,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         }
     }
     if (tid == 0) s_arrivals = 0;
+    if (SCALE) {
+        if (!bscale && tid < 2 * BK) smem[(tid >> 4) * SBUF + SA + SB + BK + (tid & 15)] = 1.f;       // no row scale: both chunks stay 1
+    }
     // prologue: tile 0 -> buffer 0, group 0 of tile 0 into registers
 #pragma unroll
     for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
