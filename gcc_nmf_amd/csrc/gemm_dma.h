@@ -92,11 +92,18 @@ __device__ __forceinline__ void gemm_barrier_arrive(unsigned counter_byte_addr) 
                  : "v"(counter_byte_addr), "v"(one)
                  : "memory");
 }
-__device__ __forceinline__ void gemm_barrier_wait(unsigned counter_byte_addr, unsigned target) {
-    unsigned seen, seen_s;
-    asm volatile("1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_ge_u32 %1, %3\n\t"
-                 "s_cbranch_scc1 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
-                 : "=&v"(seen), "=&s"(seen_s)
+// The wait in two parts: the counter is READ a few MFMAs ahead (no wait), and CHECKED where the hand-over is needed -- in the
+// usual case every wave had arrived by the time of the read and the check costs no LDS round trip; otherwise it polls.
+__device__ __forceinline__ unsigned gemm_barrier_peek(unsigned counter_byte_addr) {
+    unsigned seen;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(counter_byte_addr) : "memory");
+    return seen;
+}
+__device__ __forceinline__ void gemm_barrier_wait(unsigned counter_byte_addr, unsigned target, unsigned seen) {
+    unsigned seen_s;
+    asm volatile("s_waitcnt lgkmcnt(0)\n1:\n\tv_readfirstlane_b32 %1, %0\n\ts_cmp_ge_u32 %1, %3\n\ts_cbranch_scc1 2f\n\t"
+                 "s_sleep 1\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\ts_branch 1b\n2:"
+                 : "+v"(seen), "=&s"(seen_s)
                  : "v"(counter_byte_addr), "s"(target)
                  : "memory", "scc");
 }
@@ -643,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         GEMM_PROBE_DECL(3);
         GEMM_PROBE_DECL(4);
         GEMM_PROBE_DECL(5);
+        unsigned seen = 0;
 #ifndef GEMM_DMA_ARRIVE_E
 #define GEMM_DMA_ARRIVE_E 1        // MFMA groups (8 each) of the second k half issued before the arrival ...
 #define GEMM_DMA_WAIT_E 3          // ... and before the wait + the reads of the next tile's group 0
@@ -657,12 +665,17 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 gemm_barrier_arrive(arrivals_addr);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (e == GEMM_DMA_WAIT_E - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                seen = gemm_barrier_peek(arrivals_addr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (e == GEMM_DMA_WAIT_E) {
                 // every wave has arrived: tile t+1 is complete in LDS, and nobody reads tile t any more (its buffer is the
                 // target of the next step's pieces)
                 __builtin_amdgcn_sched_barrier(0);
                 GEMM_PROBE_SET(4);
-                gemm_barrier_wait(arrivals_addr, 4u * (unsigned)(kt + 1));
+                gemm_barrier_wait(arrivals_addr, 4u * (unsigned)(kt + 1), seen);
                 GEMM_PROBE_SET(5);
                 read_group0(ldsN);
                 __builtin_amdgcn_sched_barrier(0);
