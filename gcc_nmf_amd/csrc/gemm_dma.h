@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     };
     constexpr int NPIECES = 10;
     // how the pieces are dealt out over the 16 MFMA pairs of group 0 -- 0: all before the first MFMA; 1: one per pair;
-    // 2: two per three pairs.  Measured (64 files, K = 1024): W.H (A reduction-contiguous, B not) 0.816 / 0.698 / 0.699 ms,
-    // R.H^T (both reduction-contiguous: every piece is 16 rows x 64 B) 0.777 / 0.779 / 0.750 ms, W^T.R 0.829 / 0.829 / 0.818 ms.
+    // 2: two per three pairs.  While every piece carried a 64-bit VALU address add this mattered (W.H 0.816 / 0.698 / 0.699 ms,
+    // R.H^T 0.777 / 0.779 / 0.750); with the saddr form the three are within 2 % (0.664 / 0.654 / 0.654, 0.644 / 0.624 / 0.624).
 #ifdef GEMM_DMA_SPREAD
     constexpr int SPREAD = GEMM_DMA_SPREAD;
 #else
