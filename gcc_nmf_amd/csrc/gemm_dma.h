@@ -22,18 +22,15 @@
 typedef __attribute__((address_space(3))) void* gemm_lds_ptr;
 typedef __attribute__((address_space(1))) const void* gemm_glb_ptr;
 
-__device__ __forceinline__ void gemm_dma16(const float* src, float* lds_wave_base) {
-    // lane l lands at lds_wave_base + 16*l bytes; lds_wave_base must be wave-uniform
-    __builtin_amdgcn_global_load_lds((gemm_glb_ptr)src, (gemm_lds_ptr)lds_wave_base, 16, 0, 0);
-}
-// The same with the address split into a wave-uniform base (SGPR pair) and an unsigned 32-bit per-lane byte offset, as inline
-// asm: hipcc does not select the `saddr + voffset` form for the builtin (it adds base + offset on the VALU, per piece, and
-// keeps the offsets as 64-bit pairs).  M0 = LDS byte address of the piece (wave-uniform).
+// One LDS-DMA piece: 16 B per lane from (wave-uniform base, SGPR pair) + (unsigned 32-bit per-lane byte offset); lane l lands at
+// M0 + 16*l, M0 = LDS byte address of the piece (wave-uniform).  Inline asm: for __builtin_amdgcn_global_load_lds hipcc does
+// not select this `saddr + voffset` form -- it adds base + offset on the VALU before every piece and keeps the offsets as
+// 64-bit pairs.  (M0 is written without being declared: nothing else in these kernels uses it.)
 __device__ __forceinline__ void gemm_dma16(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
                  :
                  : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_wave_byte_addr)
-                 : "memory");     // (M0 is written; every other user of M0 here -- the builtin form above -- sets it right before its use)
+                 : "memory");
 }
 
 // A piece fetched by a few lanes only (`mask`, compile-time): exec is narrowed and restored inside the asm, so the main loop
