@@ -64,12 +64,6 @@ __device__ __forceinline__ gemm_f32x2 gemm_lds_read2_b32(unsigned byte_addr) {
     return v;
 }
 
-template <int OFF>
-__device__ __forceinline__ float gemm_lds_read_b32(unsigned byte_addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
-    return v;
-}
 // "The LDS reads issued so far have landed": an s_waitcnt followed by empty asm statements that take the destination
 // registers as in/out operands (asm volatile statements keep their order), so the compiler can neither hoist a use above
 // the wait nor copy a register before its data has arrived.  Nothing may touch a destination between the read and its tie.
@@ -478,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     GemmFrag<A_KC, TM, BM> a0, a1;
     GemmFrag<B_KC, 2, BN> b0, b1;
     gemm_f32x4 sc0 = zero4, sc1 = zero4, t4 = zero4, tb4 = zero4, ts4 = zero4, rs4 = zero4;
-    float tbx = 0.f, tby = 0.f, tbz = 0.f, tbw = 0.f;
+    gemm_f32x2 tbxy = {0.f, 0.f}, tbzw = {0.f, 0.f};
 
     const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)&s_arrivals;
     // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
@@ -509,10 +503,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 if (B_KC) {
                     tb4 = gemm_lds_read_b128<0>(lds + oTB);
                 } else {
-                    tbx = gemm_lds_read_b32<0 * 4 * BN>(lds + oTB);
-                    tby = gemm_lds_read_b32<1 * 4 * BN>(lds + oTB);
-                    tbz = gemm_lds_read_b32<2 * 4 * BN>(lds + oTB);
-                    tbw = gemm_lds_read_b32<3 * 4 * BN>(lds + oTB);
+                    tbxy = gemm_lds_read2_b32<0 * BN, 1 * BN>(lds + oTB);      // rows 4g, 4g+1 of column j (BN dwords apart)
+                    tbzw = gemm_lds_read2_b32<2 * BN, 3 * BN>(lds + oTB);
                     if (SCALE) ts4 = gemm_lds_read_b128<4 * (SA + SB + BK)>(lds + 16 * tg);
                 }
             }
@@ -543,11 +535,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             if (B_KC) {
                 gemm_tie(tb4);
             } else {
-                gemm_tie(tbx);
-                gemm_tie(tby);
-                gemm_tie(tbz);
-                gemm_tie(tbw);
-                tb4 = gemm_f32x4{tbx, tby, tbz, tbw};
+                gemm_tie(tbxy);
+                gemm_tie(tbzw);
+                tb4 = gemm_f32x4{tbxy.x, tbxy.y, tbzw.x, tbzw.y};
                 if (SCALE) {
                     gemm_tie(ts4);
                     tb4 *= ts4;
