@@ -40,9 +40,9 @@ extern "C" {
 
 int gccnmf_version(void);
 
-/* Timing-experiment knob (process-global, results become INVALID while non-zero).  key 1: ablation bits for the GEMM
- * kernels -- 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row, 16 no epilogue (DESIGN.md 'where the
- * time goes' quotes these).  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
+/* Experiment knobs (process-global).  key 1: ablation bits of the REGISTER-STAGED GEMM kernel (results become INVALID while
+ * non-zero; the LDS-DMA kernel ignores them) -- 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row,
+ * 16 no epilogue.  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
  * 2 always the 128x64 small-batch tile (results stay valid; used by the tests to cover both paths at any size).
  * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
  * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs). */
