@@ -192,9 +192,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
+    # one rank per GPU over RCCL; GCCNMF_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
+    backend = os.environ.get('GCCNMF_BENCH_BACKEND', 'nccl')
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from gcc_nmf_amd.engine import GCCNMFEngine
     from gcc_nmf_amd.synthetic import synthetic_batch
@@ -211,7 +217,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if backend == 'nccl':
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     if a.mode == 'shared-dictionary':
         return shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier)
