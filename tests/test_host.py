@@ -143,3 +143,23 @@ def test_ordered_dictionary_matches_reference_rule():
     cent = (np.arange(40)[:, None] * Wo).sum(0) / Wo.sum(0)
     assert Wo.shape == W.shape and np.all(np.diff(cent) >= 0)
     assert sorted(map(tuple, Wo.T.round(6))) == sorted(map(tuple, W.T.round(6)))       # a permutation of the atoms
+
+
+def test_bench_contract_defaults_and_loud_failure_without_gpu(monkeypatch):
+    """bench.py: no flags = 1 GPU, a handful of steps, the BASELINE workload (64 files, K = 1024, 100 iterations); without
+    a device it fails loudly (HipLibraryError) instead of timing a fallback."""
+    import importlib
+    import sys
+    import pytest
+    import torch
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    bench = importlib.import_module('bench')
+    a = bench.parse()
+    assert (a.gpus, a.files, a.dictionary_size, a.iterations, a.hop, a.seconds, a.mode) == (1, 64, 1024, 100, 256, 10.0, 'separate')
+    assert 1 <= a.steps <= 10 and a.warmup >= 1 and a.nmf_groups is None
+    assert bench.F32_MFMA_PEAK_TFLOPS == 157.3
+    if not torch.cuda.is_available():
+        from gcc_nmf_amd._hip import HipLibraryError
+        from gcc_nmf_amd.engine import GCCNMFEngine
+        with pytest.raises(HipLibraryError):
+            GCCNMFEngine(160000, dictionarySize=1024, batch=1)
