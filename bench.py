@@ -258,6 +258,12 @@ def main():
                    'nmf_file_groups_per_gpu': e.nmf_groups},
         'tdoa_indexes_as_expected': idx_ok,
     }
+    # the whole path against the f32-MFMA roofline -- algorithmic flop per stereo frame (NMF 16 F K iters + STFT,
+    # angular spectrum, scores, reconstruction, iSTFT) / peak; per GPU, so the fraction holds at any N
+    flop_per_frame = 16.0 * g.F * K * iters + 2 * 5 * 1024 * 10 + 2.0 * 128 * 2 * g.F + 3 * 2.0 * g.F * K + 3 * 2 * 2.0 * g.F * K + 3 * 2 * 5 * 1024 * 10
+    ceiling = F32_MFMA_PEAK_TFLOPS * 1e12 / flop_per_frame
+    out['end_to_end_vs_mfma_roofline'] = {'flop_per_frame': flop_per_frame, 'ceiling_frames_per_s_per_gpu': ceiling,
+                                          'frac': frames / elapsed / world / ceiling}
 
     if rank == 0:
         # host float32 samples in -> host float32 waveforms out (PCIe both ways); reported beside `value`, never as `value`
