@@ -339,8 +339,9 @@ def main():
         out['gpu_vs_cpu_tdoa_equal'] = bool(e.get_tdoa_indexes()[0].tolist() == r['idx'])
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()                      # rank 0's extra measurements are done: every rank leaves the group together
         dist.destroy_process_group()
 
 
