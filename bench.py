@@ -51,9 +51,14 @@ def parse():
     return p.parse_args()
 
 
-def kernel_timings(e, reps):
-    """Average duration of each of the five per-iteration launches, measured with HIP events recorded on
-    the stream the kernels are launched on (torch's current stream), inside real iterations."""
+def kernel_timings(e, iterations=10, launches=20):
+    """(ms per KL-NMF iteration, ms per launch of the roofline kernel), HIP events on the stream the kernels are launched on
+    (torch's current stream), whole batch per launch on one stream.
+      * the iteration: one event pair around `iterations` complete iterations (stages 1-5 back to back, as gccnmf_klnmf
+        issues them) -- event pairs around single launches add ~0.05-0.1 ms of gap each and are not used;
+      * the roofline kernel (K3: R = V / (W.H), == K1 without the lazy row scale) is a pure function of V, W, H, so it is
+        launched `launches` times back to back between one event pair.  Per-kernel averages of the other three launches:
+        the committed rocprofv3 summary (profiles/*_g1_bench_kernel_stats.csv)."""
     import torch
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import _ptr, _stream
@@ -67,26 +72,20 @@ def kernel_timings(e, reps):
     stage(0)
     for s in range(1, 6):
         stage(s)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
+    e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     torch.cuda.synchronize()
-    for r in range(reps):
-        ev[r][0].record()
+    e0.record()
+    for _ in range(iterations):
         for s in range(1, 6):
             stage(s)
-            ev[r][s].record()
-    torch.cuda.synchronize()
-    ms = np.array([[ev[r][s - 1].elapsed_time(ev[r][s]) for s in range(1, 6)] for r in range(reps)]).mean(axis=0)
-    # The dominant kernel (K3 == K1 without the row scale: R = V/(W.H)) is a pure function of V, W, H, so it can be launched
-    # back to back: one event pair around `n` launches gives its average duration without the event gaps of the loop above.
-    n = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    stage(3)
-    e0.record()
-    for _ in range(n):
-        stage(3)
     e1.record()
+    stage(3)
+    e2.record()
+    for _ in range(launches):
+        stage(3)
+    e3.record()
     torch.cuda.synchronize()
-    return ms, e0.elapsed_time(e1) / n
+    return e0.elapsed_time(e1) / iterations, e2.elapsed_time(e3) / launches
 
 
 def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
@@ -281,14 +280,8 @@ def main():
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
 
     if rank == 0 and not a.skip_roofline:
-        ms, k3_ms = kernel_timings(e, reps=5)
+        iter_ms, k3_ms = kernel_timings(e)
         flop_per_launch = 2.0 * g.F * g.K * g.N * B                          # algorithmic: F=513, N=2T, not the padded tile grid
-        names = ['K1 R=V/(W.(s*H))', 'K2 H*=W^T.R/colsum', 'K3 R=V/(W.H)', 'K4a U=R.H^T', 'K4b W update+normalise']
-        kern = {}
-        for i, nm in enumerate(names):
-            kern[nm] = {'avg_ms': float(ms[i])}
-            if i < 4:
-                kern[nm]['tflops'] = flop_per_launch / (ms[i] * 1e-3) / 1e12
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
@@ -300,9 +293,11 @@ def main():
             # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (profiles/README.md), gfx950-corrected
             out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = pmc['source']
-        out['kernels'] = kern             # in-loop event pairs: include ~0.05 ms of event gap per launch
-        out['nmf_iteration_ms'] = float(ms.sum())
-        out['nmf_gemm_tflops_per_iteration'] = 4 * flop_per_launch / (ms.sum() * 1e-3) / 1e12
+        # one KL-NMF iteration = the four dependent GEMM launches, whole batch on ONE stream, wall time between events: includes
+        # the ~40-60 us a kernel boundary costs between dependent launches (the timed steps hide those under the other file
+        # group's kernels; kernel-time sums are in the rocprofv3 summaries)
+        out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12,
+                                           'frac_of_peak': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
 
     if rank == 0 and world == 1:
         # the same parameters on ONE mixture (BASELINE config 2's shape): latency-bound, small-batch GEMM tile
