@@ -3,10 +3,13 @@ a NumPy restatement of ``gccNMF/realtime/gccNMFProcessor.py:167-275`` (GCCNMFPro
 cannot run here -- Theano is not installable) and ``gccNMF/realtime/utils.py:34-118`` (history ring buffer,
 OverlapAddProcessor).
 
-PARITY UNPINNED by reference runs: the reference has no tests and its processor needs Theano; this restatement
-follows the source line by line (dtype promotions included where they matter) and is what the HIP streaming
-path is compared against.  What it pins in turn: tests/test_rt_oracle.py checks it against an independent
-brute-force evaluation of the same formulas and against the offline functions where the two paths coincide.
+PINNED on a run of the unmodified reference: oracle/make_rt_golden.py imports the reference's GCCNMFProcessor,
+OverlapAddProcessor and SharedMemoryCircularBuffer as they are, on top of oracle/theano_stub (a NumPy-evaluated stand-in for
+the dozen Theano names the processor uses), and writes tests/golden/rt_*.npz; tests/test_rt_golden.py checks this
+restatement against them (spectrogram / coherence / arg-max bit-equal, masks and frames to 2e-6, the tracked TDOA of
+60-300 block streams block by block).  tests/test_rt_oracle.py adds an independent brute-force evaluation of the formulas.
+The low-latency extensions further down (asymmetric windows, per-frame H inference) have no reference code in this
+checkout and are marked "parity unpinned" where they are defined.
 """
 import numpy as np
 from numpy.fft import rfft, irfft
@@ -14,6 +17,14 @@ from numpy.fft import rfft, irfft
 SPEED_OF_SOUND_IN_METRES_PER_SECOND = 340.29       # gccNMF/defs.py:40
 TARGET_MODE_BOXCAR = 0                             # gccNMFProcessor.py:35-37
 TARGET_MODE_WINDOW_FUNCTION = 2
+
+
+def make_rt_dictionary(seed, numFrequencies, dictionarySize):
+    """Seeded stand-in for a pre-trained dictionary (positive, unit-norm atoms); the recipe shared by oracle/make_rt_golden.py and
+    the tests so that the goldens need not store W."""
+    rng = np.random.RandomState(seed)
+    W = rng.rand(numFrequencies, dictionarySize).astype(np.float32) + np.float32(0.02)
+    return (W / np.linalg.norm(W, axis=0)).astype(np.float32)
 
 
 class CircularHistory(object):
