@@ -52,6 +52,16 @@ def reference_pipeline(stereoSamples, sampleRate, ws, hop, D, d, S, K, iters, al
     return dict(X=X, V=V, W=W, H=H, C=C, A=A, meanA=meanA, idx=np.array([int(i) for i in idx]), G=G, M=M, S=Sp, y=y)
 
 
+def near_ties(G, below=1e-2):
+    """Sparse record of the reference's near-tied coefficient assignments: flat (k, t) positions whose two best target scores
+    differ by less than `below` relative to the best, and that relative gap.  A position that is not listed is a
+    well-separated arg-max which every implementation must reproduce exactly."""
+    srt = np.sort(np.asarray(G, np.float64), axis=0)
+    gap = (srt[-1] - srt[-2]) / np.maximum(np.abs(srt[-1]), 1e-300)
+    pos = np.flatnonzero(gap.ravel() < below)
+    return dict(tie_pos=pos.astype(np.int32), tie_gap=gap.ravel()[pos].astype(np.float32), tie_below=np.float64(below))
+
+
 def save(name, **arrays):
     path = os.path.join(OUT, name + '.npz')
     np.savez_compressed(path, **arrays)
@@ -88,18 +98,21 @@ def main():
              argmax=np.argmax(r['M'], axis=0).astype(np.uint8),
              mask_counts=r['M'].sum(axis=(1, 2)).astype(np.int64),
              S_sub=r['S'][:, :, ::8, ::5],
-             y=r['y'].astype(np.float32))
+             y=r['y'].astype(np.float32), **near_ties(r['G']))
 
     # ---- the other five mixtures + dev1 at the reference's default hop 128: summaries -----
-    for w, hop in [(WAVS[0], 128)] + [(w, 256) for w in WAVS[1:]]:
-        x, sr = R.loadMixtureSignal(os.path.join(REF_ROOT, 'data', w + '_mix.wav'))
-        r = reference_pipeline(x, sr, ws, hop, D, d, S, 128, 100)
-        print('%s hop %d: idx=%s' % (w, hop, r['idx']))
-        save('%s_hop%d_K128' % (w, hop), idx=r['idx'], meanA=r['meanA'],
-             argmax=np.argmax(r['M'], axis=0).astype(np.uint8),
-             mask_counts=r['M'].sum(axis=(1, 2)).astype(np.int64),
-             y_sub=r['y'][:, :, ::8].astype(np.float32),
-             y_rms=np.float64(np.sqrt(np.mean(r['y'].astype(np.float64) ** 2))))
+    # (SURVEY section 4 asks for K in {128, 1024} on all six)
+    for K in (128, 1024):
+        for w, hop in [(WAVS[0], 128)] + [(w, 256) for w in WAVS[1:]]:
+            x, sr = R.loadMixtureSignal(os.path.join(REF_ROOT, 'data', w + '_mix.wav'))
+            t0 = time.time()
+            r = reference_pipeline(x, sr, ws, hop, D, d, S, K, 100)
+            print('%s hop %d K=%d: idx=%s (%.1f s)' % (w, hop, K, r['idx'], time.time() - t0))
+            save('%s_hop%d_K%d' % (w, hop, K), idx=r['idx'], meanA=r['meanA'],
+                 argmax=np.argmax(r['M'], axis=0).astype(np.uint8),
+                 mask_counts=r['M'].sum(axis=(1, 2)).astype(np.int64),
+                 y_sub=r['y'][:, :, ::8].astype(np.float32),
+                 y_rms=np.float64(np.sqrt(np.mean(r['y'].astype(np.float64) ** 2))), **near_ties(r['G']))
 
     # ---- synthetic mixture i = 0 (SURVEY 8d recipe), K = 128 ------------------------------
     xs = O.synthetic_mixture(0)
@@ -107,7 +120,7 @@ def main():
     print('synthetic 0: idx=%s' % r['idx'])
     save('synthetic0_hop256_K128', x_head=xs[:, :4096], x_sum=np.float64(xs.astype(np.float64).sum()),
          idx=r['idx'], meanA=r['meanA'], argmax=np.argmax(r['M'], axis=0).astype(np.uint8),
-         y_sub=r['y'][:, :, ::8].astype(np.float32))
+         y_sub=r['y'][:, :, ::8].astype(np.float32), **near_ties(r['G']))
 
     # ---- small known-answer cases for each primitive --------------------------------------
     rng = np.random.RandomState(1234)

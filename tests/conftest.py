@@ -30,3 +30,13 @@ def golden_wav(prefix):
 @pytest.fixture(scope='session')
 def dev1():
     return golden_wav('dev1_female3_liverec_130ms_1m')
+
+
+def mask_flips(argmax, g):
+    """(number of (k, t) coefficients whose target assignment differs from the reference golden `g`, largest relative top-2
+    gap of the REFERENCE's scores among them).  SURVEY 8(c): masks must be exact except at genuine near-ties; goldens list
+    every position with a gap below `tie_below` (oracle/make_golden.py: near_ties), anything unlisted counts as gap = inf."""
+    flipped = np.flatnonzero(np.asarray(argmax).ravel() != g['argmax'].ravel())
+    gap = np.full(g['argmax'].size, np.inf)
+    gap[g['tie_pos']] = g['tie_gap']
+    return len(flipped), (float(gap[flipped].max()) if len(flipped) else 0.0)

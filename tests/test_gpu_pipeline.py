@@ -3,11 +3,24 @@ live oracle, and size-independent properties at the benchmark shape."""
 import numpy as np
 import pytest
 
-from conftest import golden, golden_wav
+from conftest import golden, golden_wav, mask_flips
 from oracle import gccnmf_oracle as O
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
+
+# coefficient masks are exact except at genuine near-ties of the reference's own scores.  The goldens list every
+# (k, t) whose top-2 relative gap is below 1e-2 (conftest.mask_flips); a flip anywhere else fails.  The device's W/H differ from
+# the reference's by ~5e-6 relative after 100 iterations (summation order), so scores move by about that much: measured on
+# MI355X the largest gap that ever flipped is 1.9e-5 (dev_D, K=1024; 0-5 flips per 637k coefficients), printed by the tests below (-s).
+TIE_LIMIT = 1e-4
+
+
+def live_gaps(G):
+    """relative top-2 gap of oracle scores G (S, K, T) -> (K, T)"""
+    srt = np.sort(np.asarray(G, np.float64), axis=0)
+    return (srt[-1] - srt[-2]) / np.maximum(np.abs(srt[-1]), 1e-300)
+
 
 WAVS = ['dev_A_1_2_3_4', 'dev_B_1_8_9_16', 'dev_C_2_7_10_15', 'dev_D_13_14_15_16', 'dev_Sq1_Co_A']
 
@@ -39,42 +52,48 @@ def test_dev1_against_reference_golden(dev1, K):
     assert rel(W[0][:, ::sub], g['W_sub']) < 1e-4 and rel(H[0][::sub, :], g['H_sub']) < 1e-4
     ang, meanA = e.get_angular()
     assert np.abs(meanA[0] - g['meanA']).max() < 1e-3
-    flips = np.mean(e.get_argmax()[0] != g['argmax'])
-    assert flips < 1e-3, flips
+    flips, worst = mask_flips(e.get_argmax()[0], g)
+    assert worst < TIE_LIMIT, (flips, worst)
     assert y.shape == (3, 2, 158976) and y.dtype == np.float32
     rms = np.sqrt(np.mean((y.astype(np.float64) - g['y']) ** 2))
-    assert rms < 1e-4, rms
-    print('dev1 K=%d: W rel %.2e H rel %.2e mask flips %.2e waveform rms %.2e' %
-          (K, rel(W[0][:, ::sub], g['W_sub']), rel(H[0][::sub, :], g['H_sub']), flips, rms))
+    assert rms < 1e-6, rms                                  # bar: 1e-4; measured 7e-9 (K=128) / 1.2e-8 (K=1024)
+    print('dev1 K=%d: W rel %.2e H rel %.2e mask flips %d (largest reference gap among them %.1e) waveform rms %.2e' %
+          (K, rel(W[0][:, ::sub], g['W_sub']), rel(H[0][::sub, :], g['H_sub']), flips, worst, rms))
 
 
-def test_all_reference_mixtures_batched():
-    """The five other reference mixtures as ONE batch of 5 (+ dev1): TDOA indexes exact for every file.
+@pytest.mark.parametrize('K', [128, 1024])
+def test_all_reference_mixtures_batched(K):
+    """The five other reference mixtures as ONE batch of 5 (+ dev1), K = 128 and K = 1024: TDOA indexes exact for every file.
     Their sources sit within 4 TDOA bins of each other (d = 1 m assumed, real spacing 5 cm), which makes
     this the sharp test of the f32 angular spectrum."""
     names = ['dev1_female3_liverec_130ms_1m'] + WAVS
     xs = np.stack([golden_wav(w)[0] for w in names])
-    e = engine(xs.shape[2], dictionarySize=128, numIterations=100, batch=len(names))
+    e = engine(xs.shape[2], dictionarySize=K, numIterations=100, batch=len(names))
     y = e.separate(xs)
     idx = e.get_tdoa_indexes()
     for i, w in enumerate(names):
-        g = golden('%s_hop256_K128' % w) if i else golden('dev1_hop256_K128')
+        g = golden('%s_hop256_K%d' % (w, K)) if i else golden('dev1_hop256_K%d' % K)
         assert idx[i].tolist() == list(g['idx']), w
         assert np.abs(e.get_angular()[1][i] - g['meanA']).max() < 1e-3
-        assert np.mean(e.get_argmax()[i] != g['argmax']) < 2e-3, w
+        flips, worst = mask_flips(e.get_argmax()[i], g)
+        assert worst < TIE_LIMIT, (w, flips, worst)
         ref = g['y'][:, :, ::8] if 'y' in g.files else g['y_sub']
         rms = np.sqrt(np.mean((y[i][:, :, ::8].astype(np.float64) - ref) ** 2))
-        assert rms < 1e-4, (w, rms)
+        assert rms < 1e-5, (w, rms)      # bar 1e-4; measured <= 2.0e-6 (a near-tie flip moves one atom of one frame)
+        print('%s K=%d: mask flips %d (largest reference gap %.1e) waveform rms %.2e' % (w, K, flips, worst, rms))
 
 
-def test_hop128_reference_default(dev1):
+@pytest.mark.parametrize('K', [128, 1024])
+def test_hop128_reference_default(dev1, K):
     x, sr = dev1
-    g = golden('dev1_female3_liverec_130ms_1m_hop128_K128')
-    e = engine(x.shape[1], sampleRate=sr, hopSize=128, dictionarySize=128, numIterations=100)
+    g = golden('dev1_female3_liverec_130ms_1m_hop128_K%d' % K)
+    e = engine(x.shape[1], sampleRate=sr, hopSize=128, dictionarySize=K, numIterations=100)
     y = e.separate(x)[0]
     assert e.get_tdoa_indexes()[0].tolist() == list(g['idx'])
     assert y.shape == (3, 2, 128 * 1242)
-    assert np.sqrt(np.mean((y[:, :, ::8].astype(np.float64) - g['y_sub']) ** 2)) < 1e-4
+    flips, worst = mask_flips(e.get_argmax()[0], g)
+    assert worst < TIE_LIMIT, (flips, worst)
+    assert np.sqrt(np.mean((y[:, :, ::8].astype(np.float64) - g['y_sub']) ** 2)) < 1e-6
 
 
 @pytest.fixture(params=[1, 2], ids=['tile-throughput', 'tile-small'])
@@ -93,8 +112,9 @@ def test_dev1_K1024_both_tiles(dev1, forced_tile):
     e = engine(x.shape[1], sampleRate=sr, dictionarySize=1024, numIterations=100)
     y = e.separate(x)[0]
     assert e.get_tdoa_indexes()[0].tolist() == [47, 72, 107]
-    assert np.mean(e.get_argmax()[0] != g['argmax']) < 1e-3
-    assert np.sqrt(np.mean((y.astype(np.float64) - g['y']) ** 2)) < 1e-4
+    flips, worst = mask_flips(e.get_argmax()[0], g)
+    assert worst < TIE_LIMIT, (flips, worst)
+    assert np.sqrt(np.mean((y.astype(np.float64) - g['y']) ** 2)) < 1e-6
 
 
 def test_synthetic_against_oracle_stagewise():
@@ -123,9 +143,36 @@ def test_synthetic_against_oracle_stagewise():
         assert np.abs(ang[0] - ang_same_C).max() < 1e-3              # the GEMM itself, on the device's own coherence
         assert e.get_tdoa_indexes()[0].tolist() == r['idx']
         assert np.abs(e.get_scores()[0] - r['G']).max() < 1e-4 * np.abs(r['G']).max()
-        assert np.mean(e.get_argmax()[0] != np.argmax(r['M'], 0)) < 2e-3
-        assert np.abs(e.get_spec()[0] - r['S']).max() < 1e-4 * np.abs(r['S']).max()
-        assert np.sqrt(np.mean((y.astype(np.float64) - r['y']) ** 2)) < 1e-4
+        flipped = e.get_argmax()[0] != np.argmax(r['M'], 0)
+        assert (live_gaps(r['G'])[flipped] < TIE_LIMIT).all(), (int(flipped.sum()), live_gaps(r['G'])[flipped].max())
+        if not flipped.any():
+            assert np.abs(e.get_spec()[0] - r['S']).max() < 1e-4 * np.abs(r['S']).max()
+        assert np.sqrt(np.mean((y.astype(np.float64) - r['y']) ** 2)) < 1e-6
+
+
+def test_benchmark_batch_against_oracle():
+    """The bench workload itself (64 synthetic 10 s files, K = 1024, 100 iterations, throughput tile, two file groups): TDOA
+    indexes of ALL 64 files against the oracle's localisation, and four files (first, last, two from the middle) through the
+    oracle's whole pipeline: masks exact up to near-ties, waveforms <= 1e-6 RMS (bar 1e-4)."""
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    xs = synthetic_batch(0, 64)
+    e = engine(160000, dictionarySize=1024, numIterations=100, batch=64)
+    y = e.separate(xs)
+    idx = e.get_tdoa_indexes()
+    freqs = np.linspace(0, 8000.0, 513)
+    for b in range(64):
+        X = O.computeComplexMixtureSpectrogram(xs[b], 1024, 256, np.hanning)
+        meanA = np.mean(O.getAngularSpectrogram(O.spectralCoherence(X), freqs, 1.0, 128), axis=-1)
+        assert idx[b].tolist() == [int(i) for i in O.estimateTargetTDOAIndexesFromAngularSpectrum(meanA, 1.0, 128, 3)], b
+    am = e.get_argmax()
+    for b in (0, 21, 42, 63):
+        r = O.runGCCNMF(xs[b], 16000, 1024, 256, 128, 1.0, 3, dictionarySize=1024, numIterations=100, return_intermediates=True)
+        flipped = am[b] != np.argmax(r['M'], 0)
+        gaps = live_gaps(r['G'])[flipped]
+        assert (gaps < TIE_LIMIT).all(), (b, int(flipped.sum()), gaps.max())
+        rms = np.sqrt(np.mean((y[b].astype(np.float64) - r['y']) ** 2))
+        assert rms < 1e-5, (b, rms)      # bar 1e-4; measured <= 1.7e-6
+        print('bench file %d: mask flips %d (largest oracle gap %.1e) waveform rms %.2e' % (b, int(flipped.sum()), gaps.max() if len(gaps) else 0, rms))
 
 
 def test_too_few_peaks_is_an_error():
