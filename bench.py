@@ -88,7 +88,7 @@ def kernel_timings(e, iterations=10, launches=20):
     return e0.elapsed_time(e1) / iterations, e2.elapsed_time(e3) / launches
 
 
-def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
+def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen=1, backend='nccl'):
     """BASELINE config 4: ONE dictionary for every file of every rank.  Columns (files) are sharded over ranks, W is
     replicated; each KL-NMF iteration is local GEMMs + one RCCL all-reduce of [num (Fp*Kp) || den (Kp)] floats."""
     import torch
@@ -101,7 +101,7 @@ def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
     local = HipSharedNMF.from_device(e.V, g.F, g.N, W0, H0)
 
     def step():
-        local.reset(W0, H0)
+        local.reset()                     # the initial factors uploaded by from_device()
         train_shared_dictionary(local, iters)
     for _ in range(a.warmup):
         step()
@@ -129,6 +129,7 @@ def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier):
             'config': {'workload': '%d files/GPU, one shared dictionary, all-reduce of %d floats per iteration' %
                                    (B, local.partial.numel()), 'files_per_gpu': B, 'dictionary_size': K, 'nmf_iterations': iters,
                        'parallelism': 'columns sharded x%d, W replicated, 1 all-reduce/iteration' % world},
+            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None,
             'dictionary_finite_unit_norm': bool(np.isfinite(W).all() and np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-4)),
         }))
     if world > 1:
@@ -180,17 +181,33 @@ def streaming_mode(a):
         'tracked_tdoa_index': p.targetTDOAIndex}))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse()
     if a.mode == 'streaming':
         return streaming_mode(a)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a.gpus)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE %d (launch with torch.distributed.run)' % (a.gpus, world), file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch exactly one rank per GPU' % (a.gpus, world))
     # one rank per GPU over RCCL; GCCNMF_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 code path
     backend = os.environ.get('GCCNMF_BENCH_BACKEND', 'nccl')
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
@@ -200,6 +217,15 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+
+    # every rank adds 1 over the data-path backend (RCCL unless GCCNMF_BENCH_BACKEND says otherwise): the job really is N ranks
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device='cuda')
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+        if ranks_seen != a.gpus:
+            raise SystemExit('bench.py: %d ranks answered the all-reduce, --gpus %d' % (ranks_seen, a.gpus))
 
     from gcc_nmf_amd.engine import GCCNMFEngine
     from gcc_nmf_amd.synthetic import synthetic_batch
@@ -222,7 +248,7 @@ def main():
                 dist.barrier()
 
     if a.mode == 'shared-dictionary':
-        return shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier)
+        return shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen, backend)
 
     for _ in range(a.warmup):
         e.run()
@@ -249,13 +275,14 @@ def main():
         'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%d x %.0f s stereo @16 kHz synthetic mixtures per GPU (SURVEY 8d recipe), 1024-pt FFT hop %d '
-                               '(F=513, T=%d/file), K=%d, %d KL-NMF iters, 128 TDOAs, 3 targets; end-to-end samples-in-HBM -> '
-                               'separated waveforms-in-HBM, independent dictionary per file' % (B, a.seconds, a.hop, g.T, K, iters),
+        'config': {'workload': 'HBM-resident (float32 samples in HBM -> separated float32 waveforms in HBM; the host-to-host rates are '
+                               'the host_to_host_* fields): %d x %.0f s stereo @16 kHz synthetic mixtures per GPU (SURVEY 8d recipe), '
+                               '1024-pt FFT hop %d (F=513, T=%d/file), K=%d, %d KL-NMF iters, 128 TDOAs, 3 targets, independent '
+                               'dictionary per file' % (B, a.seconds, a.hop, g.T, K, iters),
                    'files_per_gpu': B, 'frames_per_file': g.T, 'dictionary_size': K, 'nmf_iterations': iters,
                    'parallelism': 'file-sharded x%d, no data-path collective' % world,
                    'nmf_file_groups_per_gpu': e.nmf_groups},
-        'tdoa_indexes_as_expected': idx_ok,
+        'tdoa_indexes_as_expected': idx_ok, 'ranks_seen': ranks_seen,
     }
     # the whole path against the f32-MFMA roofline -- algorithmic flop per stereo frame (NMF 16 F K iters + STFT,
     # angular spectrum, scores, reconstruction, iSTFT) / peak; per GPU, so the fraction holds at any N
@@ -327,7 +354,10 @@ def main():
         dt = time.perf_counter() - t1
         out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
                                'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle '
-                                         '(oracle/gccnmf_oracle.py), %.1f s' % (B, g.T, dt),
+                                         '(oracle/gccnmf_oracle.py; its angular-spectrum and score contractions are GEMM restatements, '
+                                         'so it is FASTER than the reference code), %.1f s.  The unmodified reference functions on the '
+                                         'same file and parameters: 68.5 frames/s end to end on the 8 cores of the build container '
+                                         '(SURVEY section 6; it cannot travel to the GPU box)' % (B, g.T, dt),
                                'host_cpus': os.cpu_count()}
         y0 = e.y[0].cpu().numpy()
         out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))

@@ -164,15 +164,17 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 
 // ---- int16 egress (gccNMF/wavfile.py:39-48, :92-131) ---------------------------------------------------------
 // peak[g] = max |y| over the 2*L samples of group g (= one target of one file: what one wavwrite call sees).
-// Non-negative floats order like their bit patterns, so atomicMax on the uint image is exact and order independent.
+// Non-negative floats order like their bit patterns, so atomicMax on the uint image is exact and order independent -- and
+// +Inf / NaN images (>= 0x7F800000) rank above every finite value, so a non-finite sample always surfaces in peak[g]: the host
+// checks for it (the reference's wavwrite would write platform-defined garbage for NaN; here NaN -> 0, +-Inf clip, no rescale).
 __global__ __launch_bounds__(256) void pcm_peak_kernel(const float* __restrict__ y, long group_len, unsigned int* __restrict__ peak) {
     const long g = blockIdx.y;
     const float* yg = y + g * group_len;
-    float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < group_len; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(yg[i]));
+    unsigned int m = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < group_len; i += (long)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(yg[i])));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(peak + g, __float_as_uint(m));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak + g, m);
 }
 
 // y [g][2][L] float -> pcm [g][L][2] int16: clip protection (peak >= 1 -> x / peak * 0.99), x * 32768, clip, truncate.
@@ -183,10 +185,12 @@ __global__ __launch_bounds__(256) void pcm_pack_kernel(const float* __restrict__
     if (m >= L) return;
     const float pk = __uint_as_float(peak[g]);
     float a = y[(g * 2) * L + m], b = y[(g * 2 + 1) * L + m];
-    if (pk >= 1.f) {
+    if (pk >= 1.f && peak[g] < 0x7F800000u) {
         a = a / pk * 0.99f;
         b = b / pk * 0.99f;
     }
+    a = (a == a) ? a : 0.f;
+    b = (b == b) ? b : 0.f;
     a = fminf(fmaxf(a * 32768.f, -32768.f), 32767.f);
     b = fminf(fmaxf(b * 32768.f, -32768.f), 32767.f);
     pcm[g * L + m] = make_short2((short)(int)a, (short)(int)b);

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
-from .engine import Geometry, padded, _ptr, _stream
+from .engine import Geometry, padded, _ptr, _stream, _on_device
 
 
 def shard_files(num_files, world_size, rank):
@@ -76,6 +76,7 @@ class HipSharedNMF(object):
         self.Hd = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), dev)
         self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self.N, self.K, self.B), dtype=torch.float32, device=dev)
         self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=dev)
+        self._W0d, self._H0d = self.Wd.clone(), self.Hd.clone()
 
     @classmethod
     def from_device(cls, V_dev, F, N, W0, H0_files, sparsityAlpha=0, epsilon=1e-16):
@@ -97,29 +98,38 @@ class HipSharedNMF(object):
         self.reset(W0, H0_files)
         return self
 
-    def reset(self, W0, H0_files):
-        """(Re)load the initial factors; the padding stays zero."""
-        if not hasattr(self, '_W0d'):
-            g = self.g
+    @_on_device
+    def reset(self, W0=None, H0_files=None):
+        """(Re)load initial factors; the padding stays zero.  New arrays are uploaded (and remembered); ``reset()`` without
+        arguments restores the factors of the last upload without touching the host."""
+        g = self.g
+        if W0 is not None:
             self._W0d = padded(np.asarray(W0, np.float32), (g.Fp, g.Kp), self.device)
+        if H0_files is not None:
             self._H0d = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), self.device)
+        if not hasattr(self, '_W0d') or not hasattr(self, '_H0d'):
+            raise ValueError('reset() without arguments needs initial factors from an earlier reset(W0, H0_files)')
         self.Wd.copy_(self._W0d)
         self.Hd.copy_(self._H0d)
 
+    @_on_device
     def begin(self):
         _hip.check(self.lib.gccnmf_klnmf_shared_begin(_ptr(self.Wd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
                    'gccnmf_klnmf_shared_begin')
 
+    @_on_device
     def step_a(self):
         _hip.check(self.lib.gccnmf_klnmf_shared_step_a(_ptr(self.V), _ptr(self.Wd), _ptr(self.Hd), _ptr(self.ws), _ptr(self.partial),
                                                        self.F, self.N, self.K, self.B, self.alpha, self.eps, _stream()),
                    'gccnmf_klnmf_shared_step_a')
         return self.partial
 
+    @_on_device
     def step_b(self, partial):
         _hip.check(self.lib.gccnmf_klnmf_shared_step_b(_ptr(self.Wd), _ptr(self.ws), _ptr(partial), self.F, self.N, self.K, self.B,
                                                        _stream()), 'gccnmf_klnmf_shared_step_b')
 
+    @_on_device
     def finish(self):
         _hip.check(self.lib.gccnmf_klnmf_shared_finish(_ptr(self.Hd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
                    'gccnmf_klnmf_shared_finish')

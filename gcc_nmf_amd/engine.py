@@ -21,8 +21,20 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _on_device(method):
+    """The C library launches on the CURRENT HIP device: make the object's device current for the duration of the call."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
+            return method(self, *args, **kwargs)
+    return wrapper
 
 
 def num_frames(n_samples, n_fft, hop):
@@ -156,6 +168,7 @@ class GCCNMFEngine(object):
             self.pcm_out = None
 
     # ---- stages (each asynchronous on the current torch stream) ---------------------------------
+    @_on_device
     def stft(self):
         g = self.g
         if self.pcm_in is not None:       # int16 interleaved frames straight from the wav data chunk
@@ -167,6 +180,7 @@ class GCCNMFEngine(object):
                                                self.batch, _ptr(self.window), _ptr(self.twiddle), _ptr(self.X), _ptr(self.V),
                                                _ptr(self.CC), _stream()), 'gccnmf_stft_stereo')
 
+    @_on_device
     def pack_pcm16(self):
         """y -> int16 interleaved [batch][S][L][2] with wavwrite's clip protection per target (wavfile.py:39-48)."""
         g = self.g
@@ -176,6 +190,7 @@ class GCCNMFEngine(object):
         _hip.check(self.lib.gccnmf_pack_pcm16(_ptr(self.y), self.batch * g.S, self.L, _ptr(self.pcm_peak), _ptr(self.pcm_out), _stream()),
                    'gccnmf_pack_pcm16')
 
+    @_on_device
     def klnmf(self):
         g = self.g
         self.W.copy_(self.W0.unsqueeze(0).expand_as(self.W))
@@ -198,6 +213,7 @@ class GCCNMFEngine(object):
             done.record(st)
             main.wait_event(done)
 
+    @_on_device
     def localize(self):
         g = self.g
         _hip.check(self.lib.gccnmf_angular_spectrogram(_ptr(self.CC), _ptr(self.trig), g.F, g.T, g.D, self.batch, _ptr(self.ang),
@@ -205,18 +221,21 @@ class GCCNMFEngine(object):
         _hip.check(self.lib.gccnmf_pick_tdoa_peaks(_ptr(self.mean_ang), g.D, g.Dp, g.S, self.batch, _ptr(self.tdoa_idx),
                                                    _ptr(self.status), _stream()), 'gccnmf_pick_tdoa_peaks')
 
+    @_on_device
     def masks(self):
         g = self.g
         _hip.check(self.lib.gccnmf_target_scores_masks(_ptr(self.CC), _ptr(self.trig), _ptr(self.tdoa_idx), _ptr(self.W), g.F, g.T,
                                                        g.K, g.D, g.S, self.batch, _ptr(self.ws_scores), _ptr(self.scores),
                                                        _ptr(self.argmax), _stream()), 'gccnmf_target_scores_masks')
 
+    @_on_device
     def reconstruct(self):
         g = self.g
         _hip.check(self.lib.gccnmf_reconstruct(_ptr(self.W), _ptr(self.H), _ptr(self.argmax), 0, _ptr(self.X), _ptr(self.V), g.F,
                                                g.T, g.K, g.S, self.batch, _ptr(self.ws_rec), _ptr(self.spec), _stream()),
                    'gccnmf_reconstruct')
 
+    @_on_device
     def istft(self):
         g = self.g
         gain = np.float32(self.hop / float(self.n_fft) * 2)           # gccNMFFunctions.py:155
@@ -224,6 +243,7 @@ class GCCNMFEngine(object):
                                              _ptr(self.twiddle), gain, 1, _ptr(self.frames), _ptr(self.y), _stream()),
                    'gccnmf_istft_ola')
 
+    @_on_device
     def run(self):
         """samples already in ``self.x`` -> separated waveforms in ``self.y`` (all on device, asynchronous)."""
         self.stft()
@@ -234,6 +254,7 @@ class GCCNMFEngine(object):
         self.istft()
 
     # ---- host <-> device -------------------------------------------------------------------------
+    @_on_device
     def upload(self, stereoSamples):
         x = np.asarray(stereoSamples, dtype=np.float32)
         if x.ndim == 2:
@@ -245,6 +266,7 @@ class GCCNMFEngine(object):
         self.pcm_in = None
         self.x.copy_(torch.from_numpy(np.ascontiguousarray(x)))
 
+    @_on_device
     def upload_pcm16(self, pcm):
         """(batch, n, 2) int16 interleaved stereo frames, exactly as scipy.io.wavfile.read returns them (no host conversion)."""
         pcm = np.asarray(pcm)
@@ -256,6 +278,7 @@ class GCCNMFEngine(object):
             self.pcm_in = torch.zeros((self.batch, self.n_samples, 2), dtype=torch.int16, device=self.device)
         self.pcm_in.copy_(torch.from_numpy(np.ascontiguousarray(pcm)))
 
+    @_on_device
     def separate_pcm16(self, pcm):
         """int16 frames in -> int16 frames out: (batch, n, 2) -> (batch, S, hop*(T-1), 2), i.e. loadMixtureSignal ...
         saveTargetSignalEstimates (runGCCNMF.py:35-54) minus the file system, with both wav conversions on the device."""
@@ -264,8 +287,10 @@ class GCCNMFEngine(object):
         self.pack_pcm16()
         out = self.pcm_out.cpu().numpy()
         self.check_status()
+        self.check_pcm_finite()
         return out
 
+    @_on_device
     def separate(self, stereoSamples):
         """(batch, 2, n) float32 host samples -> (batch, S, 2, hop*(T-1)) float32 host waveforms."""
         self.upload(stereoSamples)
@@ -288,7 +313,8 @@ class GCCNMFEngine(object):
                 self._pipe = dict(x=torch.zeros_like(self.x), y=torch.zeros_like(self.y),
                                   hx=[torch.zeros(self.x.shape, dtype=torch.float32).pin_memory() for _ in range(2)],
                                   hy=[torch.zeros(self.y.shape, dtype=torch.float32).pin_memory() for _ in range(2)],
-                                  hs=[torch.zeros(self.status.shape, dtype=self.status.dtype).pin_memory() for _ in range(2)])
+                                  hs=[torch.zeros(self.status.shape, dtype=self.status.dtype).pin_memory() for _ in range(2)],
+                                  ds=[torch.zeros_like(self.status) for _ in range(2)])
             xs, ys = [self.x, self._pipe['x']], [self.y, self._pipe['y']]
             hx, hy, status = self._pipe['hx'], self._pipe['hy'], self._pipe['hs']
             ev_in = [torch.cuda.Event() for _ in range(2)]
@@ -322,11 +348,12 @@ class GCCNMFEngine(object):
                     compute.wait_event(ev_out[slot])                     # batch i-2's waveforms have left this y buffer
                     self.x, self.y, self.pcm_in = xs[slot], ys[slot], None
                     self.run()
-                    ev_done[slot].record(compute)
+                    self._pipe['ds'][slot].copy_(self.status)            # per-slot snapshot ON the compute stream: batch i+1's
+                    ev_done[slot].record(compute)                        # localize() rewrites self.status before s_out has copied it
                     with torch.cuda.stream(s_out):
                         s_out.wait_event(ev_done[slot])
                         hy[slot].copy_(ys[slot], non_blocking=True)
-                        status[slot].copy_(self.status, non_blocking=True)
+                        status[slot].copy_(self._pipe['ds'][slot], non_blocking=True)
                         ev_out[slot].record(s_out)
                     pending.append(slot)
                 while pending:
@@ -335,6 +362,14 @@ class GCCNMFEngine(object):
                 torch.cuda.synchronize(dev)
                 self.x, self.y = xs[0], ys[0]
 
+    @_on_device
+    def check_pcm_finite(self):
+        """After pack_pcm16(): a NaN / Inf sample in a waveform shows up in that group's peak image (csrc/fft.hip)."""
+        bad = (self.pcm_peak.cpu().numpy().view(np.uint32) >= 0x7F800000).reshape(self.batch, self.g.S)
+        if bad.any():
+            raise ValueError('non-finite samples in the separated waveforms of file(s) %s' % np.nonzero(bad.any(axis=1))[0].tolist())
+
+    @_on_device
     def check_status(self):
         st = self.status.cpu().numpy()
         if st.any():

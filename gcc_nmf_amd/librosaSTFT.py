@@ -62,6 +62,16 @@ def _window_vector(window, win_length, n_fft, inverse=False):
     return pad_center(w, n_fft)
 
 
+SUPPORTED_N_FFT = (64, 128, 256, 512, 1024, 2048)
+
+
+def _check_n_fft(n_fft):
+    """The device FFT is a radix-2 kernel that keeps eight frames of one workgroup in LDS: powers of two from 64 to 2048
+    (the reference accepts any n_fft; 4096 would need more than the 160 KB of LDS per CU)."""
+    if int(n_fft) not in SUPPORTED_N_FFT:
+        raise ParameterError('n_fft={} is not supported by the HIP STFT/iSTFT: use one of {}'.format(n_fft, SUPPORTED_N_FFT))
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _hip.HipLibraryError('no ROCm device visible: gcc_nmf_amd has no CPU fallback')
@@ -83,6 +93,7 @@ def _check_frames(y, n_fft, hop_length):
 
 def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
     """One packed complex FFT per frame carries both real signals (y1 may be None)."""
+    _check_n_fft(n_fft)
     w = _window_vector(window, win_length, n_fft)
     chans = []
     for y in (y0, y1):
@@ -128,6 +139,7 @@ def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
     specs = np.asarray(specs)
     nsig, F, T = specs.shape
     n_fft = 2 * (F - 1)
+    _check_n_fft(n_fft)
     w = _window_vector(window, win_length, n_fft, inverse=True)
     lib, dev = _hip.lib(), _device()
     g = Geometry(F, T, 1)

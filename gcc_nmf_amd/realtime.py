@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from .engine import padded, fft_twiddles, _ptr, _stream
+from .engine import padded, fft_twiddles, _ptr, _stream, _on_device
 
 SPEED_OF_SOUND_IN_METRES_PER_SECOND = 340.29
 TARGET_MODE_BOXCAR = 0                   # gccNMFProcessor.py:35-37
@@ -34,6 +34,8 @@ class GCCNMFProcessor(object):
                  microphoneSeparationInMetres, localizationEnabled, localizationWindowSize, gccPHATHistory=None, tdoaHistory=None,
                  inputSpectrogramHistory=None, outputSpectrogramHistory=None, coefficientMaskHistories=None, numTDOAs=64,
                  numTDOAHistory=128):
+        if int(windowSize) not in (64, 128, 256, 512, 1024, 2048, 4096):
+            raise ValueError('windowSize=%r is not supported by the HIP frame processor: a power of two from 64 to 4096' % (windowSize,))
         self.lib = _hip.lib()
         self.device = _device()
         self.sampleRate, self.windowSize, self.numTimePerChunk = sampleRate, int(windowSize), int(numTimePerChunk)
@@ -50,6 +52,7 @@ class GCCNMFProcessor(object):
         self.reset()
 
     # ---- reference API ------------------------------------------------------------------------------------------
+    @_on_device
     def reset(self):
         """:233-270 (buildTheanoFunctions): tables and buffers for the current dictionary / TDOA grid."""
         dev = self.device
@@ -76,6 +79,7 @@ class GCCNMFProcessor(object):
         self.dTarget = torch.from_numpy(self._target_host.copy()).to(dev)
         self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
 
+    @_on_device
     def setTargetTDOARange(self, targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor):
         """:272-275"""
         self._target_host = np.array([targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor], np.float32)
@@ -85,6 +89,7 @@ class GCCNMFProcessor(object):
     def targetTDOAIndex(self):
         return float(self.dTarget[0].item())
 
+    @_on_device
     def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode):
         _hip.check(self.lib.gccnmf_rt_process_block(
             _ptr(block_in), _ptr(block_out), _ptr(in_ring), _ptr(out_ring), _ptr(self.dX), _ptr(self.dY), _ptr(self.dC), _ptr(self.dHMask),
@@ -93,6 +98,7 @@ class GCCNMFProcessor(object):
             self.numAtom, self.Kp, self.numTDOAs, self.Dp, self.numTDOAHistory, int(self.targetMode), int(bool(self.separationEnabled)),
             int(bool(self.localizationEnabled)), self.localizationWindowSize, frames_mode, _stream()), 'gccnmf_rt_process_block')
 
+    @_on_device
     def processFrames(self, windowedSamples):
         """:201-231.  (2, windowSize, Tc) windowed-sample frames -> (2, windowSize, Tc) processed frames (float32)."""
         ws = np.asarray(windowedSamples, np.float32)
@@ -105,6 +111,7 @@ class GCCNMFProcessor(object):
         return self.dFramesOut.cpu().numpy().transpose(0, 2, 1)
 
     # ---- device results of the last call, in the reference's shapes --------------------------------------------------
+    @_on_device
     def intermediates(self):
         F, K, D = self.numFrequencies, self.numAtom, self.numTDOAs
         return dict(X=torch.view_as_complex(self.dX).cpu().numpy(), C=torch.view_as_complex(self.dC).cpu().numpy(),
@@ -119,6 +126,9 @@ class StreamingGCCNMF(object):
     def __init__(self, processor, hopSize, blockSize):
         if blockSize % hopSize or blockSize // hopSize != processor.numTimePerChunk:
             raise ValueError('blockSize/hopSize must equal the processor\'s numTimePerChunk')
+        if blockSize > 512 or 8 * blockSize < processor.windowSize + (processor.numTimePerChunk - 1) * hopSize:
+            raise ValueError('blockSize=%d is not supported: the 8-block device rings (utils.py:87-92) hold at most 512 samples per '
+                             'block and must cover one window' % blockSize)
         self.p, self.hopSize, self.blockSize = processor, int(hopSize), int(blockSize)
         dev = processor.device
         self.in_ring = torch.zeros((2, 8 * blockSize), dtype=torch.float32, device=dev)

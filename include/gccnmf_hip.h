@@ -58,7 +58,10 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
  *   x        [batch][2][n_samples] float32 (file stride x_stride floats)
  *   window   [n_fft] float32 analysis window (numpy.hanning(n_fft) for the reference path)
  *   twiddle  [n_fft/2] complex: exp(-2j*pi*k/n_fft), computed in float64 on the host
- *   X, V, CC as in the geometry table; V or CC may be NULL to skip that output. */
+ *   X, V, CC as in the geometry table; V or CC may be NULL to skip that output.
+ * LIMITS (the reference accepts any size): n_fft must be a power of two in [64, 2048] -- the radix-2 kernel keeps eight
+ * frames per workgroup in LDS, n_fft = 4096 would exceed the 160 KB per CU -> GCCNMF_ERR_UNSUPPORTED; other sizes
+ * GCCNMF_ERR_ARG.  The same holds for gccnmf_istft_ola.  The Python layer raises ParameterError naming the sizes. */
 int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
                        const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
 
@@ -70,7 +73,9 @@ int gccnmf_stft_stereo_pcm16(const short* pcm, long frame_stride, int n_samples,
 
 /* wav egress on the device: y [groups][2][L] float32 -> pcm [groups][L][2] int16 with wavwrite's clip protection per
  * group (peak >= 1 -> rescale to 0.99) and float2pcm's clip + truncation (gccNMF/wavfile.py:39-48, :92-131).  One group
- * = one target of one file = one wavwrite call.  peak_scratch: `groups` uint32 of device scratch. */
+ * = one target of one file = one wavwrite call.  peak_scratch: `groups` uint32 of device scratch; on return it holds the bit
+ * image of each group's peak |y|, and an image >= 0x7F800000 means the group contained NaN / Inf samples (NaN is written as 0,
+ * +-Inf clips, no rescale; the reference's result is platform-defined there) -- the caller should treat it as an error. */
 int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scratch, short* pcm, void* stream);
 
 /* KL-NMF multiplicative updates, independent dictionary per file.
@@ -166,6 +171,8 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
  * windows.  Replaces GCCNMFProcessor.processFrames (gccNMF/realtime/gccNMFProcessor.py:201-270, a Theano graph in the
  * reference) together with OverlapAddProcessor.processFrames (gccNMF/realtime/utils.py:99-116) and the gccPHAT history /
  * online localisation (:214-222, utils.py:34-70).  Six launches on `stream`, no host synchronisation.
+ * LIMITS: windowSize a power of two in [64, 4096]; streaming mode needs blockSize <= 512 (the two 8-block rings are shifted
+ * by one 1024-thread workgroup holding 8 samples per thread) and 8*blockSize >= one window -> GCCNMF_ERR_UNSUPPORTED.
  *   block_in / block_out [2][blockSize]            new samples in, the block two blocks old out (utils.py:116)
  *   in_ring / out_ring   [2][8*blockSize]          state: the reference's 8-block buffers
  *   X, Y [2][F][Tc] complex, C [F][Tc] complex     rfft (not conjugated), masked spectrogram, PHAT coherence

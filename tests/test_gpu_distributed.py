@@ -99,3 +99,76 @@ def test_pretraining_cache_roundtrip(tmp_path):
     assert np.linalg.norm(W - Wr) < 1e-3 * np.linalg.norm(Wr)
     d = P.getDictionariesW(1024, [32], ordered=True)
     assert list(d) == ['Pretrained', 'Random'] and d['Pretrained'][32].shape == (513, 32)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_ranks_hip_shards_over_gloo_on_one_gpu(tmp_path):
+    """Two PROCESSES, each with a HIP shard of the files, one real all-reduce per iteration (gloo; both ranks on GPU 0): every
+    rank ends with the same W, equal to the single-process result over all files to summation order."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from shared_rank_worker import problem
+    F, K, N, B, iters = 513, 1024, 128, 8, 12
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'tests', 'shared_rank_worker.py'), str(tmp_path)] + [str(v) for v in (F, K, N, B, iters)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(2)]
+    H = np.concatenate([np.load(tmp_path / ('H_rank%d.npy' % i)) for i in range(2)], axis=1)
+    assert np.array_equal(W[0], W[1])
+    V = problem(F, [N] * B, 11)
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    one = train_shared_dictionary(HipSharedNMF(V, W0, H0), iters)
+    assert np.linalg.norm(W[0] - one.W()) < 1e-5 * np.linalg.norm(one.W())
+    assert np.linalg.norm(H - np.concatenate(one.H(), axis=1)) < 1e-5 * np.linalg.norm(H)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run, and the JSON line
+    reports the ranks that answered an all-reduce (here over gloo, two ranks sharing the one GPU of the test box)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['GCCNMF_BENCH_BACKEND'] = 'gloo'
+    common = ['--files', '4', '--seconds', '2', '--iterations', '5', '--dictionary-size', '128', '--steps', '1', '--warmup', '0',
+              '--skip-cpu-baseline', '--skip-roofline']
+    for mode in ('separate', 'shared-dictionary'):
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--mode', mode] + common, env=env,
+                           capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+        assert line['n_gpus'] == 2 and line['ranks_seen'] == 2, line
+    # a launcher environment that disagrees with --gpus is an error, not a warning
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2'] + common, env=env2, capture_output=True, text=True,
+                       timeout=600, cwd=REPO)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_shared_reset_reloads_new_factors():
+    """reset(W0, H0) with NEW arrays must use them; reset() restores the last upload."""
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors
+    F, K, N, B = 129, 32, 40, 2
+    V = _problem(F, K, [N] * B, seed=5)
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    s = HipSharedNMF(V, W0, H0)
+    assert np.array_equal(s.W(), W0)
+    W1 = (W0 * 0.5).astype(np.float32)
+    s.reset(W1, [h * 2 for h in H0])
+    assert np.array_equal(s.W(), W1) and np.array_equal(s.H()[1], H0[1] * 2)
+    s.begin(); s.step_b(s.step_a()); s.finish()
+    assert not np.array_equal(s.W(), W1)
+    s.reset()
+    assert np.array_equal(s.W(), W1)

@@ -359,3 +359,25 @@ def test_klnmf_repeats_are_bitwise_identical():
     for _ in range(12):
         e1.klnmf()
         assert torch.equal(e1.W, W1)
+
+
+def test_pcm16_egress_reports_non_finite_waveforms():
+    """A NaN / Inf in a separated waveform must not become arbitrary PCM silently: the peak image flags it."""
+    n = 20000
+    x = O.synthetic_mixture(4, numSamples=n)
+    e = engine(n, dictionarySize=16, numIterations=3)
+    e.separate(x)
+    e.pack_pcm16()
+    e.check_pcm_finite()
+    clean = e.pcm_out.cpu().numpy().copy()
+    e.y[0, 1, 0, 77] = float('nan')
+    e.y[0, 2, 1, 5] = float('inf')
+    e.pack_pcm16()
+    with pytest.raises(ValueError, match='non-finite'):
+        e.check_pcm_finite()
+    out = e.pcm_out.cpu().numpy()
+    assert out[0, 1, 77, 0] == 0 and out[0, 2, 5, 1] == 32767                 # NaN -> 0, +Inf clips
+    assert np.array_equal(out[0, 0], clean[0, 0])                             # the other groups are untouched
+    mask = np.ones_like(out[0, 1], bool)
+    mask[77, 0] = False
+    assert np.array_equal(out[0, 1][mask], clean[0, 1][mask])                 # no rescale of a group with a NaN peak
