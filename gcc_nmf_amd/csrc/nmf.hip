@@ -10,11 +10,16 @@
 // The compensating rescale H *= norms (:81) is NOT a separate pass over H: it is the vector s,
 // applied while K1 stages its B operand and inside K2's epilogue (which rewrites H anyway).
 // gccnmf_klnmf materialises it once after the last iteration.
-#include "gemm_dma.h"
+extern int gccnmf_tune_ring_depth;
+#include "gemm_ring.h"
 
 int gccnmf_tune_ablate = 0;
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
+int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
+int gccnmf_tune_ring_depth = 0;    // 0 auto (deep ring when the launch fits one workgroup per CU), else 6 / 10
+int gccnmf_tune_wh_splits = 2;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
+int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
@@ -32,6 +37,18 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 3) {
         gccnmf_tune_dma = value ? 1 : 0;
+        return GCCNMF_OK;
+    }
+    if (key == 4) {
+        gccnmf_tune_ring = value ? 1 : 0;
+        return GCCNMF_OK;
+    }
+    if (key == 7 && (value == 0 || value == 6 || value == 10)) {
+        gccnmf_tune_ring_depth = value;
+        return GCCNMF_OK;
+    }
+    if ((key == 5 || key == 6) && (value == 1 || value == 2 || value == 4)) {
+        (key == 5 ? gccnmf_tune_wh_splits : gccnmf_tune_rht_splits) = value;
         return GCCNMF_OK;
     }
     return GCCNMF_ERR_ARG;
@@ -165,9 +182,115 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
     }
 }
 
+// The same update in ONE pass for launches of a few files (the two-pass kernel above re-reads W and every U partial, 64 dependent
+// round trips per thread: 50 us for one file at K = 1024): 16 atoms per workgroup as float4 columns x 64 row phases, the
+// R <= 17 rows of a thread stay in registers between the norm and the store, all loads of a thread are independent.
+// Column reductions: xor-shuffles over the 16 row phases of a wave, then 4 waves through LDS (fixed order: deterministic).
+template <int R, int NSPLIT>
+__global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __restrict__ W, const float* __restrict__ U,
+                                                                   const float* __restrict__ rowsumH, float* __restrict__ colsumW,
+                                                                   float* __restrict__ hscale, int F, int K, int Kp, long sW, long sU,
+                                                                   long sVec, long sRowsum, long sSplitU, long sSplitR) {
+    constexpr int nsplit = NSPLIT;
+    __shared__ float red[4][16];
+    __shared__ float s_norm[16];
+    const int chunks = Kp / 16;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int c4 = threadIdx.x & 3, q = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+    const int k0 = ch * 16 + 4 * c4;
+    const bool v0 = k0 < K, v1 = k0 + 1 < K, v2 = k0 + 2 < K, v3 = k0 + 3 < K;      // padded atoms stay exactly zero
+    float* Wb = W + b * sW;
+    const float* Ub = U + b * sU;
+    float4 rs = *(const float4*)(rowsumH + b * sRowsum + k0);
+#pragma unroll
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float4 t = *(const float4*)(rowsumH + b * sRowsum + sp * sSplitR + k0);
+        rs.x += t.x; rs.y += t.y; rs.z += t.z; rs.w += t.w;
+    }
+    // every load of the thread is issued before the first use: rows beyond F re-read row F-1 (clamped, always in bounds) and are
+    // masked afterwards -- conditional loads would serialise into R dependent round trips
+    float4 wt[R], uu[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long i = (long)min(q + 64 * r, F - 1) * Kp + k0;
+        wt[r] = *(const float4*)(Wb + i);
+        uu[r] = *(const float4*)(Ub + i);
+    }
+    float4 tt[NSPLIT > 1 ? NSPLIT - 1 : 1][R];          // the partials of a split-K launch: all in flight together, added in ascending order
+#pragma unroll
+    for (int sp = 1; sp < nsplit; ++sp)
+#pragma unroll
+        for (int r = 0; r < R; ++r) tt[sp - 1][r] = *(const float4*)(Ub + sp * sSplitU + (long)min(q + 64 * r, F - 1) * Kp + k0);
+#pragma unroll
+    for (int sp = 1; sp < nsplit; ++sp)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uu[r].x += tt[sp - 1][r].x; uu[r].y += tt[sp - 1][r].y; uu[r].z += tt[sp - 1][r].z; uu[r].w += tt[sp - 1][r].w;
+        }
+    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = q + 64 * r < F;
+        const float4 w = wt[r], u = uu[r];
+        wt[r] = make_float4((ok && v0) ? w.x * (u.x / rs.x) : 0.f, (ok && v1) ? w.y * (u.y / rs.y) : 0.f, (ok && v2) ? w.z * (u.z / rs.z) : 0.f,
+                            (ok && v3) ? w.w * (u.w / rs.w) : 0.f);
+        ss.x = fmaf(wt[r].x, wt[r].x, ss.x);
+        ss.y = fmaf(wt[r].y, wt[r].y, ss.y);
+        ss.z = fmaf(wt[r].z, wt[r].z, ss.z);
+        ss.w = fmaf(wt[r].w, wt[r].w, ss.w);
+    }
+    auto reduce16 = [&](float4 v) {        // sum over the 16 row phases of this wave (lane bits 2..5)
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+            v.x += __shfl_xor(v.x, o);
+            v.y += __shfl_xor(v.y, o);
+            v.z += __shfl_xor(v.z, o);
+            v.w += __shfl_xor(v.w, o);
+        }
+        return v;
+    };
+    ss = reduce16(ss);
+    if ((threadIdx.x & 63) < 4) *(float4*)&red[wave][4 * c4] = ss;
+    __syncthreads();
+    if (threadIdx.x < 16) s_norm[threadIdx.x] = sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    __syncthreads();
+    const float4 nm = *(const float4*)&s_norm[4 * c4];
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int f = q + 64 * r;
+        if (f < F) {
+            const float4 wn = make_float4(v0 ? wt[r].x / nm.x : 0.f, v1 ? wt[r].y / nm.y : 0.f, v2 ? wt[r].z / nm.z : 0.f,
+                                          v3 ? wt[r].w / nm.w : 0.f);
+            *(float4*)(Wb + (long)f * Kp + k0) = wn;
+            cs.x += wn.x; cs.y += wn.y; cs.z += wn.z; cs.w += wn.w;
+        }
+    }
+    cs = reduce16(cs);
+    __syncthreads();
+    if ((threadIdx.x & 63) < 4) *(float4*)&red[wave][4 * c4] = cs;
+    __syncthreads();
+    if (threadIdx.x < 16 && ch * 16 + (int)threadIdx.x < K) {
+        const int k = ch * 16 + threadIdx.x;
+        colsumW[b * sVec + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        hscale[b * sVec + k] = s_norm[threadIdx.x];
+    }
+}
+
 static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,
                            int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s, int nsplit = 1,
                            long sSplitU = 0, long sSplitR = 0) {
+    if ((long)batch * (Kp / 64) < 256 && gccnmf_tune_ring && F <= 64 * 9 && (nsplit == 1 || nsplit == 2 || nsplit == 4)) {
+        const dim3 grid(batch * (Kp / 16));
+#define GCCNMF_ONEPASS(NS_) hipLaunchKernelGGL((nmf_update_w_onepass_kernel<9, NS_>), grid, dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, K, \
+                                               Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR)
+        if (nsplit == 1) GCCNMF_ONEPASS(1);
+        else if (nsplit == 2) GCCNMF_ONEPASS(2);
+        else GCCNMF_ONEPASS(4);
+#undef GCCNMF_ONEPASS
+        GCCNMF_CHECK_LAUNCH();
+        return GCCNMF_OK;
+    }
     if ((long)batch * (Kp / 64) >= 256) {
         hipLaunchKernelGGL(nmf_update_w_kernel<64>, dim3(batch * (Kp / 64)), dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, Fp, K,
                            Kp, sW, sU, sVec, sRowsum, nsplit, sSplitU, sSplitR);
@@ -227,6 +350,11 @@ static bool small_batch_tile(const GemmArgs& a) {
 template <bool A_KC, bool B_KC, int EPI>
 static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
     const bool tall = a.M > 128;
+    if (small_batch_tile(a) && gccnmf_tune_ring) {
+        if (A_KC) return tail ? gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);
+        if (tail) return GCCNMF_ERR_ARG;
+        return gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);
+    }
     if (small_batch_tile(a)) {
         if (A_KC) return tail ? gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, A_KC, 1>(a, s) : gccnmf_launch_gemm<4, 1, A_KC, B_KC, EPI, false, 1>(a, s);
         if (tail) return GCCNMF_ERR_ARG;
@@ -351,52 +479,69 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
 #define GCCNMF_SPLITS 4
 
 // R[f][n] = V[f][n] / (P_0 + P_1 + ... )[f][n] on the valid F x N region only (R's padding must stay zero)
+// one float4 per thread; columns >= N of the last float4 are written as 0 (not 0/0)
 __global__ __launch_bounds__(256) void nmf_div_partials_kernel(const float* __restrict__ V, const float* __restrict__ P, long sP,
                                                                int nsplit, int F, int N, int Np, float* __restrict__ R) {
-    const int n = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (n >= N || f >= F) return;
+    const int n4 = Np / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)F * n4) return;
+    const int f = (int)(idx / n4), n = 4 * (int)(idx - (long)f * n4);
+    if (n >= N) return;
     const long i = (long)f * Np + n;
-    float d = P[i];
-    for (int sp = 1; sp < nsplit; ++sp) d += P[sp * sP + i];
-    R[i] = V[i] / d;
+    float4 d = *(const float4*)(P + i);
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const float4 t = *(const float4*)(P + sp * sP + i);
+        d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+    }
+    const float4 v = *(const float4*)(V + i);
+    *(float4*)(R + i) = make_float4(v.x / d.x, n + 1 < N ? v.y / d.y : 0.f, n + 2 < N ? v.z / d.z : 0.f, n + 3 < N ? v.w / d.w : 0.f);
 }
 
 // reduction length (padded) worth cutting: at least 8 k-tiles per part
-static bool single_file_split(const NmfGeom& g, int batch, int reduction) {
-    return batch == 1 && gccnmf_tune_tile_policy != 1 && g.Fm > 128 && reduction >= GCCNMF_SPLITS * 128;
+static bool single_file_split(const NmfGeom& g, int batch, int reduction, int splits) {
+    return batch == 1 && splits > 1 && gccnmf_tune_tile_policy != 1 && g.Fm > 128 && reduction >= GCCNMF_SPLITS * 128 &&
+           (reduction / 16) % splits == 0;
 }
 
 // P_part = W[:, part] . (hscale * H)[part, :]   (EPI_STORE incl. the VALU tail row), then R = V / sum_part P_part
 static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W, const float* H, const float* hscale, float* P, float* R,
                                hipStream_t s) {
-    const int len = g.Kp / GCCNMF_SPLITS;                    // atoms per part (multiple of 16)
+    const int nsplit = gccnmf_tune_wh_splits;
+    const int len = g.Kp / nsplit;                           // atoms per part (multiple of 16)
     GemmArgs a = {};
     a.A = W; a.sA = len; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = (long)len * g.Np; a.ldb = g.Np; a.b_clamp = g.Np - 4;
     a.M = g.Fm; a.N = g.N; a.Kd = len;
-    a.batch = GCCNMF_SPLITS; a.xcd_affine = 0;
+    a.batch = nsplit; a.xcd_affine = 0;
     a.bscale = hscale; a.s_bscale = len;
     a.tail_row = g.F - 1;
     a.C = P; a.sC = g.sV; a.ldc = g.Np;
-    int rc = g.tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false, 1>(a, s);
+    int rc;
+    if (gccnmf_tune_ring)
+        rc = g.tail ? gccnmf_launch_gemm_ring<true, false, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_STORE, false>(a, s);
+    else
+        rc = g.tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false, 1>(a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(nmf_div_partials_kernel, dim3(gccnmf_ceil_div(g.N, 256), g.F), dim3(256), 0, s, V, P, g.sV, GCCNMF_SPLITS, g.F, g.N,
-                       g.Np, R);
+    hipLaunchKernelGGL(nmf_div_partials_kernel, dim3((unsigned)(((long)g.F * (g.Np / 4) + 255) / 256)), dim3(256), 0, s, V, P, g.sV, nsplit, g.F,
+                       g.N, g.Np, R);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
 
 // U_part = R[:, part] . H[:, part]^T, rowsum_part = sum_{n in part} H   (consumed by nmf_update_w_kernel with nsplit parts)
 static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, float* Upart, float* rowsum_part, hipStream_t s) {
-    const int len = g.Np / GCCNMF_SPLITS;                    // columns per part (multiple of 16; beyond N both operands are zero)
+    const int nsplit = gccnmf_tune_rht_splits;
+    const int len = g.Np / nsplit;                           // columns per part (multiple of 16; beyond N both operands are zero)
     GemmArgs a = {};
     a.A = R; a.sA = len; a.lda = g.Np; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = len; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = len;
-    a.batch = GCCNMF_SPLITS; a.xcd_affine = 0;
+    a.batch = nsplit; a.xcd_affine = 0;
     a.tail_row = g.F - 1;
     a.rowsumB = rowsum_part; a.s_rowsumB = g.Kp;
     a.C = Upart; a.sC = g.sU; a.ldc = g.Kp;
+    if (gccnmf_tune_ring)
+        return g.tail ? gccnmf_launch_gemm_ring<true, true, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, true, EPI_STORE, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }
 
@@ -423,7 +568,8 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* hscale = rowsumH + (long)batch * g.Kp;
     float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
-    const bool split_wh = single_file_split(g, batch, g.Kp), split_rht = single_file_split(g, batch, g.Np);
+    const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
+    const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
     const int xcd = (flags & 1) ? 0 : 1;
     const int vec_grid = batch * (g.Kp / 64);
     switch (stage) {
@@ -446,7 +592,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
         case 5:
             if (split_rht)
                 return launch_update_w(W, parts, rowsum_parts, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch,
-                                       s, GCCNMF_SPLITS, g.sU, (long)g.Kp);
+                                       s, gccnmf_tune_rht_splits, g.sU, (long)g.Kp);
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
             return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s);
         case 6:

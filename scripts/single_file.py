@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""One mixture alone (BASELINE config 2's shape: 10 s, K = 1024, 100 iterations): wall time per file for the tuning variants of the
+latency path.  usage (GPU box): python scripts/single_file.py [--profile]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch                                            # noqa: E402
+from gcc_nmf_amd import _hip                            # noqa: E402
+from gcc_nmf_amd.engine import GCCNMFEngine             # noqa: E402
+from gcc_nmf_amd.synthetic import synthetic_batch       # noqa: E402
+
+lib = _hip.lib()
+xs = synthetic_batch(0, 1)
+K = int(os.environ.get('K', '1024'))
+e = GCCNMFEngine(160000, dictionarySize=K, numIterations=100, batch=1)
+e.upload(xs[0])
+
+
+def run(label, reps=3):
+    e.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    e.klnmf()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e.klnmf()
+    torch.cuda.synchronize()
+    nmf = (time.perf_counter() - t0) / reps * 1e3
+    print('%-40s %7.2f ms per file  (KL-NMF alone %7.2f ms = %.1f us per iteration), tdoa %s' % (label, ms, nmf, nmf * 10, e.get_tdoa_indexes()[0].tolist()), flush=True)
+    return e.y.clone()
+
+
+if '--profile' in sys.argv:
+    run('default', 2)
+    sys.exit(0)
+lib.gccnmf_set_tuning(4, 0)
+y_old = run('register-staged (round 1)')
+lib.gccnmf_set_tuning(4, 1)
+for wh in (1, 2, 4):
+    for rht in (2, 4):
+        lib.gccnmf_set_tuning(5, wh)
+        lib.gccnmf_set_tuning(6, rht)
+        y = run('ring, W.H splits %d, R.H^T splits %d' % (wh, rht))
+        print('    waveform rms vs register-staged: %.2e' % float(((y - y_old) ** 2).mean().sqrt()))
