@@ -186,18 +186,21 @@ __global__ __launch_bounds__(256) void nmf_update_w_kernel(float* __restrict__ W
 // round trips per thread: 50 us for one file at K = 1024): 16 atoms per workgroup as float4 columns x 64 row phases, the
 // R <= 17 rows of a thread stay in registers between the norm and the store, all loads of a thread are independent.
 // Column reductions: xor-shuffles over the 16 row phases of a wave, then 4 waves through LDS (fixed order: deterministic).
-template <int R, int NSPLIT>
+template <int AT, int NSPLIT>
 __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __restrict__ W, const float* __restrict__ U,
                                                                    const float* __restrict__ rowsumH, float* __restrict__ colsumW,
                                                                    float* __restrict__ hscale, int F, int K, int Kp, long sW, long sU,
                                                                    long sVec, long sRowsum, long sSplitU, long sSplitR) {
     constexpr int nsplit = NSPLIT;
-    __shared__ float red[4][16];
-    __shared__ float s_norm[16];
-    const int chunks = Kp / 16;
+    constexpr int L4 = AT / 4;                 // float4 lanes per row segment
+    constexpr int PH = 256 / L4;               // row phases per workgroup (PH / 4 per wave)
+    constexpr int R = (64 * 9 + PH - 1) / PH;  // rows per thread for F <= 576
+    __shared__ float red[4][AT];
+    __shared__ float s_norm[AT];
+    const int chunks = Kp / AT;
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    const int c4 = threadIdx.x & 3, q = threadIdx.x >> 2, wave = threadIdx.x >> 6;
-    const int k0 = ch * 16 + 4 * c4;
+    const int c4 = threadIdx.x % L4, q = threadIdx.x / L4, wave = threadIdx.x >> 6;
+    const int k0 = ch * AT + 4 * c4;
     const bool v0 = k0 < K, v1 = k0 + 1 < K, v2 = k0 + 2 < K, v3 = k0 + 3 < K;      // padded atoms stay exactly zero
     float* Wb = W + b * sW;
     const float* Ub = U + b * sU;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
     float4 wt[R], uu[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long i = (long)min(q + 64 * r, F - 1) * Kp + k0;
+        const long i = (long)min(q + PH * r, F - 1) * Kp + k0;
         wt[r] = *(const float4*)(Wb + i);
         uu[r] = *(const float4*)(Ub + i);
     }
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
 #pragma unroll
     for (int sp = 1; sp < nsplit; ++sp)
 #pragma unroll
-        for (int r = 0; r < R; ++r) tt[sp - 1][r] = *(const float4*)(Ub + sp * sSplitU + (long)min(q + 64 * r, F - 1) * Kp + k0);
+        for (int r = 0; r < R; ++r) tt[sp - 1][r] = *(const float4*)(Ub + sp * sSplitU + (long)min(q + PH * r, F - 1) * Kp + k0);
 #pragma unroll
     for (int sp = 1; sp < nsplit; ++sp)
 #pragma unroll
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
     float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bool ok = q + 64 * r < F;
+        const bool ok = q + PH * r < F;
         const float4 w = wt[r], u = uu[r];
         wt[r] = make_float4((ok && v0) ? w.x * (u.x / rs.x) : 0.f, (ok && v1) ? w.y * (u.y / rs.y) : 0.f, (ok && v2) ? w.z * (u.z / rs.z) : 0.f,
                             (ok && v3) ? w.w * (u.w / rs.w) : 0.f);
@@ -239,9 +242,9 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
         ss.z = fmaf(wt[r].z, wt[r].z, ss.z);
         ss.w = fmaf(wt[r].w, wt[r].w, ss.w);
     }
-    auto reduce16 = [&](float4 v) {        // sum over the 16 row phases of this wave (lane bits 2..5)
+    auto reduce_wave = [&](float4 v) {        // sum over the row phases of this wave (lane bits log2(L4) .. 5)
 #pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
+        for (int o = L4; o < 64; o <<= 1) {
             v.x += __shfl_xor(v.x, o);
             v.y += __shfl_xor(v.y, o);
             v.z += __shfl_xor(v.z, o);
@@ -249,16 +252,16 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
         }
         return v;
     };
-    ss = reduce16(ss);
-    if ((threadIdx.x & 63) < 4) *(float4*)&red[wave][4 * c4] = ss;
+    ss = reduce_wave(ss);
+    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = ss;
     __syncthreads();
-    if (threadIdx.x < 16) s_norm[threadIdx.x] = sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (threadIdx.x < AT) s_norm[threadIdx.x] = sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
     __syncthreads();
     const float4 nm = *(const float4*)&s_norm[4 * c4];
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int f = q + 64 * r;
+        const int f = q + PH * r;
         if (f < F) {
             const float4 wn = make_float4(v0 ? wt[r].x / nm.x : 0.f, v1 ? wt[r].y / nm.y : 0.f, v2 ? wt[r].z / nm.z : 0.f,
                                           v3 ? wt[r].w / nm.w : 0.f);
@@ -266,12 +269,12 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
             cs.x += wn.x; cs.y += wn.y; cs.z += wn.z; cs.w += wn.w;
         }
     }
-    cs = reduce16(cs);
+    cs = reduce_wave(cs);
     __syncthreads();
-    if ((threadIdx.x & 63) < 4) *(float4*)&red[wave][4 * c4] = cs;
+    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = cs;
     __syncthreads();
-    if (threadIdx.x < 16 && ch * 16 + (int)threadIdx.x < K) {
-        const int k = ch * 16 + threadIdx.x;
+    if (threadIdx.x < AT && ch * AT + (int)threadIdx.x < K) {
+        const int k = ch * AT + threadIdx.x;
         colsumW[b * sVec + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         hscale[b * sVec + k] = s_norm[threadIdx.x];
     }
@@ -281,12 +284,20 @@ static int launch_update_w(float* W, const float* U, const float* rowsumH, float
                            int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s, int nsplit = 1,
                            long sSplitU = 0, long sSplitR = 0) {
     if ((long)batch * (Kp / 64) < 256 && gccnmf_tune_ring && F <= 64 * 9 && (nsplit == 1 || nsplit == 2 || nsplit == 4)) {
-        const dim3 grid(batch * (Kp / 16));
-#define GCCNMF_ONEPASS(NS_) hipLaunchKernelGGL((nmf_update_w_onepass_kernel<9, NS_>), grid, dim3(256), 0, s, W, U, rowsumH, colsumW, hscale, F, K, \
-                                               Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR)
-        if (nsplit == 1) GCCNMF_ONEPASS(1);
-        else if (nsplit == 2) GCCNMF_ONEPASS(2);
-        else GCCNMF_ONEPASS(4);
+        // 16 atoms per workgroup (64-byte row segments); 8 (twice the workgroups, 32-byte segments) measured slower: 13.0 vs 11.4 us for one
+        // file at K = 1024 -- kept selectable for experiments (tuning key 1 = 64)
+#define GCCNMF_ONEPASS(AT_, NS_) hipLaunchKernelGGL((nmf_update_w_onepass_kernel<AT_, NS_>), dim3(batch * (Kp / AT_)), dim3(256), 0, s, W, U, rowsumH, \
+                                                    colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR)
+        const bool narrow = gccnmf_tune_ablate == 64;
+        if (narrow) {
+            if (nsplit == 1) GCCNMF_ONEPASS(8, 1);
+            else if (nsplit == 2) GCCNMF_ONEPASS(8, 2);
+            else GCCNMF_ONEPASS(8, 4);
+        } else {
+            if (nsplit == 1) GCCNMF_ONEPASS(16, 1);
+            else if (nsplit == 2) GCCNMF_ONEPASS(16, 2);
+            else GCCNMF_ONEPASS(16, 4);
+        }
 #undef GCCNMF_ONEPASS
         GCCNMF_CHECK_LAUNCH();
         return GCCNMF_OK;
