@@ -52,6 +52,7 @@ SIGNATURES = {
     'gccnmf_istft_ola': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
                                  c_void_p, c_void_p, c_void_p]),
     'gccnmf_rt_process_block': (c_int, [c_void_p] * 19 + [c_int] * 13 + [c_void_p]),
+    'gccnmf_rt_process_block_ll': (c_int, [c_void_p] * 23 + [c_int] * 15 + [c_void_p]),
     'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),
     'gccnmf_debug_mfma_peak': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'gccnmf_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -679,13 +679,13 @@ int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* 
     NmfGeom g = make_geom(F, N, K);
     SharedWs w = carve_shared(workspace, g, batch);
     int rc;
-    if ((rc = launch_wh_div(g, V, W, 0, H, w.hscale, 0, w.R, batch, 0, s))) return rc;
-    if ((rc = launch_update_h(g, W, 0, w.R, H, w.hscale, 0, w.colsumW, 0, sparsity_alpha, epsilon, batch, 0, s))) return rc;
-    // H now carries the previous normalisation: the lazy scale is spent
-    hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.hscale, 1.f, (long)g.Kp);
-    GCCNMF_CHECK_LAUNCH();
-    if ((rc = launch_wh_div(g, V, W, 0, H, nullptr, 0, w.R, batch, 0, s))) return rc;
-    if ((rc = launch_rht(g, w.R, H, w.Upart, w.rowsum_part, batch, 0, s))) return rc;
+    // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
+    // through that XCD's L2), exactly as the per-file-dictionary path does
+    if ((rc = launch_wh_div(g, V, W, 0, H, w.hscale, 0, w.R, batch, 1, s))) return rc;
+    if ((rc = launch_update_h(g, W, 0, w.R, H, w.hscale, 0, w.colsumW, 0, sparsity_alpha, epsilon, batch, 1, s))) return rc;
+    // (H now carries the previous normalisation; K3 below takes no scale, and step_b rewrites hscale before anyone reads it again)
+    if ((rc = launch_wh_div(g, V, W, 0, H, nullptr, 0, w.R, batch, 1, s))) return rc;
+    if ((rc = launch_rht(g, w.R, H, w.Upart, w.rowsum_part, batch, 1, s))) return rc;
     hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)gccnmf_ceil_div((int)g.sU, 256)), dim3(256), 0, s, w.Upart, g.sU,
                        batch, g.sU, partial);
     GCCNMF_CHECK_LAUNCH();

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void rt_tfmask_kernel(const float* __restrict_
 
 // ---- rt_synth: single workgroup; frames in order (their output ranges overlap) ----------------------------------------
 __global__ __launch_bounds__(FFT_NT) void rt_synth_kernel(const float2* __restrict__ Y, int N, int logN, int start0, int start_step,
-                                                          int accumulate, int Tc, int ring, int B, const float* __restrict__ window,
-                                                          const float2* __restrict__ twiddle, float* __restrict__ out_ring,
-                                                          float* __restrict__ block_out) {
+                                                          int accumulate, int Tc, int ring, int B, int out_delay,
+                                                          const float* __restrict__ window, const float2* __restrict__ twiddle,
+                                                          float* __restrict__ out_ring, float* __restrict__ block_out) {
     extern __shared__ __attribute__((aligned(16))) float2 rt_smem[];
     float2* z = rt_smem;
     float2* tw = rt_smem + N;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(FFT_NT) void rt_synth_kernel(const float2* __restri
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * B; i += FFT_NT) {
         const int c = i / B, s = i - c * B;
-        block_out[i] = out_ring[c * ring + ring - 3 * B + s];                         // utils.py:116
+        block_out[i] = out_ring[c * ring + ring - (out_delay + 1) * B + s];           // utils.py:116 (out_delay = 2 there)
     }
 }
 
@@ -301,22 +301,107 @@ __global__ __launch_bounds__(1024) void rt_localize_kernel(const float2* __restr
     if (threadIdx.x == 0) hist_pos[0] = pos;
 }
 
+// ---- per-frame coefficient inference (numHUpdates > 0): KL-NMF H updates with W fixed -------------------------------------------
+// gccNMF/gccNMFFunctions.py:76 with W constant (sparsityAlpha = 0):  h <- h * (W^T (v / (W h))) / (W^T 1),  h0 = 1, per channel
+// and frame, v = |X_c[:, t]|.  The reference's processor accepts numHUpdates and never uses it (gccNMFProcessor.py:168); with h = 1
+// the mask below is exactly its tfMask (:267-269), so numHUpdates = 0 reproduces the reference and n > 0 is the low-latency
+// notebook's "NMF coefficients are inferred frame-by-frame" (README.md:74).  Columns: col = 2 * t + c, ncol = 2 * Tc.
+__global__ __launch_bounds__(256) void rt_fill_kernel(float* __restrict__ p, float v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// r[f][col] = |X_c[f][t]| / sum_k W[f][k] h[k][col]; one wave per frequency row, grid = ceil(F/4)
+__global__ __launch_bounds__(256) void rt_wh_kernel(const float* __restrict__ W, const float* __restrict__ Hc, const float2* __restrict__ X,
+                                                    float* __restrict__ Rv, int F, int K, int Kp, int Tc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + wave;
+    if (f >= F) return;
+    const int ncol = 2 * Tc;
+    const float* Wr = W + (long)f * Kp;
+    for (int col = 0; col < ncol; ++col) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], Hc[(long)k * ncol + col], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const int t = col >> 1, c = col & 1;
+            const float2 x = X[((long)c * F + f) * Tc + t];
+            Rv[(long)f * ncol + col] = hypotf(x.x, x.y) / s;
+        }
+    }
+}
+
+// h[k][col] *= (sum_f W[f][k] r[f][col]) / colsumW[k]; 64 atoms x 4 frequency phases per workgroup, grid = Kp/64
+__global__ __launch_bounds__(256) void rt_hupdate_kernel(const float* __restrict__ W, const float* __restrict__ Rv,
+                                                         const float* __restrict__ colsumW, float* __restrict__ Hc, int F, int K, int Kp,
+                                                         int Tc) {
+    __shared__ float red[256];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
+    const int ncol = 2 * Tc;
+    for (int col = 0; col < ncol; ++col) {
+        float s = 0.f;
+        for (int f = q; f < F; f += 4) s = fmaf(W[(long)f * Kp + k], Rv[(long)f * ncol + col], s);
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (q == 0 && k < K) {
+            const float num = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+            Hc[(long)k * ncol + col] *= num / colsumW[k];
+        }
+        __syncthreads();
+    }
+}
+
+// per-channel mask with inferred coefficients: m_c[f][t] = sum_k W h_c HMask / sum_k W h_c;  Y_c = m_c X_c;  tfMask [2][F][Tc]
+__global__ __launch_bounds__(256) void rt_tfmask_h_kernel(const float* __restrict__ W, const float* __restrict__ HMask,
+                                                          const float* __restrict__ Hc, int F, int K, int Kp, int Tc,
+                                                          const float2* __restrict__ X, float2* __restrict__ Y, float* __restrict__ tfMask) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + wave;
+    if (f >= F) return;
+    const int ncol = 2 * Tc;
+    const float* Wr = W + (long)f * Kp;
+    for (int col = 0; col < ncol; ++col) {
+        const int t = col >> 1, c = col & 1;
+        float num = 0.f, den = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float wh = Wr[k] * Hc[(long)k * ncol + col];
+            den += wh;
+            num = fmaf(wh, HMask[(long)k * Tc + t], num);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            num += __shfl_xor(num, o);
+            den += __shfl_xor(den, o);
+        }
+        if (lane == 0) {
+            const float m = num / den;
+            tfMask[((long)c * F + f) * Tc + t] = m;
+            const float2 a = X[((long)c * F + f) * Tc + t];
+            Y[((long)c * F + f) * Tc + t] = make_float2(m * a.x, m * a.y);
+        }
+    }
+}
+
 extern "C" {
 
 // Every buffer is passed explicitly (allocation lives with the host, gcc_nmf_amd/realtime.py).
 //   frames_mode = 0: streaming.  block_in [2][B] -> 8-block input buffer -> Tc windows -> ... -> overlap-add -> block_out [2][B]
 //   frames_mode = 1: the reference's GCCNMFProcessor.processFrames on its own: in_ring = windowed-sample frames [2][Tc][N]
 //                    in, out_ring = processed frames [2][Tc][N] out, no shift / overlap-add (block_in, block_out unused).
-int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
-                            float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
-                            float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
-                            const float* twiddle, int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp,
-                            int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
-                            int localization_window, int frames_mode, void* stream) {
+int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
+                               float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
+                               float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
+                               const float* synthesis_window, const float* twiddle, const float* colsumW, float* Hcoef, float* Rv,
+                               int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp, int numTDOAHistory,
+                               int target_mode, int separation_enabled, int localization_enabled, int localization_window,
+                               int frames_mode, int numHUpdates, int out_delay_blocks, void* stream) {
     const int logN = ilog2_exact(windowSize);
     if (!in_ring || !out_ring || !X || !Y || !C || !HMask || !tfMask || !hist || !hist_pos || !target || !W || !cosT || !sinT ||
-        !window || !twiddle || (!frames_mode && (!block_in || !block_out)))
+        !window || !synthesis_window || !twiddle || (!frames_mode && (!block_in || !block_out)))
         return GCCNMF_ERR_ARG;
+    if (numHUpdates < 0 || (numHUpdates > 0 && (!colsumW || !Hcoef || !Rv)) || out_delay_blocks < 1 || out_delay_blocks > 7) return GCCNMF_ERR_ARG;
     if (logN < 6 || logN > 12 || hopSize < 1 || blockSize < hopSize || blockSize % hopSize || K < 1 || Kp % 64 || Kp < K || D < 1 ||
         D > 1024 || Dp % 32 || Dp < D || numTDOAHistory < 1 || localization_window < 1 || localization_window > numTDOAHistory)
         return GCCNMF_ERR_ARG;
@@ -338,12 +423,27 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
         hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 64, Tc), dim3(256), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
                            target, target_mode, HMask, argmaxTDOA);
         GCCNMF_CHECK_LAUNCH();
-        hipLaunchKernelGGL(rt_tfmask_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, HMask, F, K, Kp, Tc, (const float2*)X,
-                           (float2*)Y, tfMask);
-        GCCNMF_CHECK_LAUNCH();
+        if (numHUpdates == 0) {
+            hipLaunchKernelGGL(rt_tfmask_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, HMask, F, K, Kp, Tc, (const float2*)X,
+                               (float2*)Y, tfMask);
+            GCCNMF_CHECK_LAUNCH();
+        } else {
+            hipLaunchKernelGGL(rt_fill_kernel, dim3(gccnmf_ceil_div(Kp * 2 * Tc, 256)), dim3(256), 0, s, Hcoef, 1.f, Kp * 2 * Tc);
+            GCCNMF_CHECK_LAUNCH();
+            for (int it = 0; it < numHUpdates; ++it) {
+                hipLaunchKernelGGL(rt_wh_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, Hcoef, (const float2*)X, Rv, F, K, Kp, Tc);
+                GCCNMF_CHECK_LAUNCH();
+                hipLaunchKernelGGL(rt_hupdate_kernel, dim3(Kp / 64), dim3(256), 0, s, W, Rv, colsumW, Hcoef, F, K, Kp, Tc);
+                GCCNMF_CHECK_LAUNCH();
+            }
+            hipLaunchKernelGGL(rt_tfmask_h_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, HMask, Hcoef, F, K, Kp, Tc,
+                               (const float2*)X, (float2*)Y, tfMask);
+            GCCNMF_CHECK_LAUNCH();
+        }
     }
     hipLaunchKernelGGL(rt_synth_kernel, dim3(1), dim3(FFT_NT), lds, s, (const float2*)(separation_enabled ? Y : X), windowSize, logN,
-                       start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, window, (const float2*)twiddle, out_ring, block_out);
+                       start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, out_delay_blocks, synthesis_window, (const float2*)twiddle,
+                       out_ring, block_out);
     GCCNMF_CHECK_LAUNCH();
     int Dq = 64;
     while (Dq < D) Dq *= 2;                 // power of two so that 1024 % Dq == 0
@@ -351,6 +451,20 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
                        numTDOAHistory, hist_pos, localization_enabled, localization_window, target, gccphat);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+// The reference's processor as it is: one window for analysis and synthesis (:186-187), no coefficient inference (numHUpdates is
+// accepted and unused there, :168), the block two blocks old handed out (utils.py:116).
+int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
+                            float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
+                            float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
+                            const float* twiddle, int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp,
+                            int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
+                            int localization_window, int frames_mode, void* stream) {
+    return gccnmf_rt_process_block_ll(block_in, block_out, in_ring, out_ring, X, Y, C, HMask, argmaxTDOA, tfMask, hist, hist_pos, target,
+                                      gccphat, W, cosT, sinT, window, window, twiddle, nullptr, nullptr, nullptr, windowSize, hopSize,
+                                      blockSize, K, Kp, D, Dp, numTDOAHistory, target_mode, separation_enabled, localization_enabled,
+                                      localization_window, frames_mode, 0, 2, stream);
 }
 
 }  // extern "C"

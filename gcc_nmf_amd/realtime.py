@@ -19,6 +19,22 @@ TARGET_MODE_MULTIPLE = 1
 TARGET_MODE_WINDOW_FUNCTION = 2
 
 
+def asymmetricWindows(windowSize, synthesisSize):
+    """Low-latency analysis / synthesis window pair (README.md:74-78; construction after Mauler & Martin 2007): a long analysis window
+    for spectral resolution, a synthesis window on the last ``synthesisSize`` samples only.  analysis * synthesis is the periodic Hann
+    of length synthesisSize, which overlap-adds to 1 at hopSize = synthesisSize / 2: algorithmic latency synthesisSize samples."""
+    K, M = int(windowSize), int(synthesisSize) // 2
+    if synthesisSize % 2 or not 0 < 2 * M <= K:
+        raise ValueError('synthesisSize must be even and at most windowSize')
+    n = np.arange(K, dtype=np.float64)
+    long_rise = np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * n / (2 * (K - M))))) if K > M else np.ones(K)
+    short = 0.5 * (1.0 - np.cos(2.0 * np.pi * (n - (K - 2 * M)) / (2 * M)))
+    analysis = np.where(n < K - M, long_rise, np.sqrt(np.maximum(short, 0.0)))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        synthesis = np.where(n < K - 2 * M, 0.0, np.where(n < K - M, short / long_rise, np.sqrt(np.maximum(short, 0.0))))
+    return analysis.astype(np.float32), synthesis.astype(np.float32)
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _hip.HipLibraryError('no ROCm device visible: gcc_nmf_amd has no CPU fallback')
@@ -33,14 +49,17 @@ class GCCNMFProcessor(object):
     def __init__(self, sampleRate, windowSize, numTimePerChunk, dictionariesW, dictionaryType, dictionarySize, numHUpdates,
                  microphoneSeparationInMetres, localizationEnabled, localizationWindowSize, gccPHATHistory=None, tdoaHistory=None,
                  inputSpectrogramHistory=None, outputSpectrogramHistory=None, coefficientMaskHistories=None, numTDOAs=64,
-                 numTDOAHistory=128):
+                 numTDOAHistory=128, analysisWindow=None, synthesisWindow=None):
         if int(windowSize) not in (64, 128, 256, 512, 1024, 2048, 4096):
             raise ValueError('windowSize=%r is not supported by the HIP frame processor: a power of two from 64 to 4096' % (windowSize,))
         self.lib = _hip.lib()
         self.device = _device()
         self.sampleRate, self.windowSize, self.numTimePerChunk = sampleRate, int(windowSize), int(numTimePerChunk)
         self.dictionariesW, self.dictionaryType, self.dictionarySize = dictionariesW, dictionaryType, dictionarySize
-        self.numHUpdates = numHUpdates                    # accepted and unused, exactly as in the reference (:168)
+        # The reference accepts numHUpdates and never uses it (:168).  Here 0 (the reference's config default, config.py:73) IS the
+        # reference's mask; n > 0 runs n KL-NMF coefficient updates per frame with W fixed (gccNMFFunctions.py:76) -- the "NMF
+        # coefficients are inferred frame-by-frame" of README.md:74, for which the checkout holds no code (parity unpinned).
+        self.numHUpdates = int(numHUpdates or 0)
         self.microphoneSeparationInMetres = microphoneSeparationInMetres
         self.localizationEnabled, self.localizationWindowSize = localizationEnabled, int(localizationWindowSize)
         self.numTDOAs, self.numTDOAHistory = int(numTDOAs), int(numTDOAHistory)
@@ -48,6 +67,12 @@ class GCCNMFProcessor(object):
         self.targetMode = TARGET_MODE_WINDOW_FUNCTION
         self.windowFunction = np.sqrt(np.hamming(self.windowSize).astype(np.float32))[:, np.newaxis]      # :186
         self.synthesisWindowFunction = self.windowFunction
+        if analysisWindow is not None:                    # low-latency extension: separate (asymmetric) windows, see asymmetricWindows()
+            a = np.asarray(analysisWindow, np.float32)
+            sy = np.asarray(synthesisWindow if synthesisWindow is not None else analysisWindow, np.float32)
+            if a.shape != (self.windowSize,) or sy.shape != (self.windowSize,):
+                raise ValueError('analysisWindow / synthesisWindow must have windowSize samples')
+            self.windowFunction, self.synthesisWindowFunction = a[:, np.newaxis], sy[:, np.newaxis]
         self._target_host = np.array([10.0, 2.0, 1.0, 0.0], np.float32)                                   # :195-198
         self.reset()
 
@@ -71,10 +96,13 @@ class GCCNMFProcessor(object):
         self.dCos = padded(np.ascontiguousarray(self.expJOmegaTau.real), (F, self.Dp), dev)
         self.dSin = padded(np.ascontiguousarray(-self.expJOmegaTau.imag), (F, self.Dp), dev)
         self.dWindow = torch.from_numpy(np.ascontiguousarray(self.windowFunction[:, 0])).to(dev)
+        self.dSynthWindow = torch.from_numpy(np.ascontiguousarray(self.synthesisWindowFunction[:, 0])).to(dev)
+        self.dColsum = padded(self.W.sum(axis=0, dtype=np.float32), (self.Kp,), dev)          # sum_f W: denominator of the H update
+        self.dHcoef, self.dRv = z(self.Kp, Tc, 2), z(F, Tc, 2)
         self.dTwiddle = torch.from_numpy(fft_twiddles(self.windowSize)).to(dev)
         self.dX, self.dY, self.dC = z(2, F, Tc, 2), z(2, F, Tc, 2), z(F, Tc, 2)
         self.dHMask, self.dArgmax = z(self.Kp, Tc), z(self.Kp, Tc, dtype=torch.int32)
-        self.dTfMask, self.dGccPhat = z(F, Tc), z(D, Tc)
+        self.dTfMask, self.dGccPhat = z(2, F, Tc), z(D, Tc)          # tfMask: [F][Tc] used without coefficient inference, [2][F][Tc] with
         self.dHist, self.dHistPos = z(D, self.numTDOAHistory), z(1, dtype=torch.int32)
         self.dTarget = torch.from_numpy(self._target_host.copy()).to(dev)
         self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
@@ -90,13 +118,15 @@ class GCCNMFProcessor(object):
         return float(self.dTarget[0].item())
 
     @_on_device
-    def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode):
-        _hip.check(self.lib.gccnmf_rt_process_block(
+    def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode, out_delay_blocks=2):
+        _hip.check(self.lib.gccnmf_rt_process_block_ll(
             _ptr(block_in), _ptr(block_out), _ptr(in_ring), _ptr(out_ring), _ptr(self.dX), _ptr(self.dY), _ptr(self.dC), _ptr(self.dHMask),
             _ptr(self.dArgmax), _ptr(self.dTfMask), _ptr(self.dHist), _ptr(self.dHistPos), _ptr(self.dTarget), _ptr(self.dGccPhat),
-            _ptr(self.dW), _ptr(self.dCos), _ptr(self.dSin), _ptr(self.dWindow), _ptr(self.dTwiddle), self.windowSize, hop, block,
+            _ptr(self.dW), _ptr(self.dCos), _ptr(self.dSin), _ptr(self.dWindow), _ptr(self.dSynthWindow), _ptr(self.dTwiddle),
+            _ptr(self.dColsum), _ptr(self.dHcoef), _ptr(self.dRv), self.windowSize, hop, block,
             self.numAtom, self.Kp, self.numTDOAs, self.Dp, self.numTDOAHistory, int(self.targetMode), int(bool(self.separationEnabled)),
-            int(bool(self.localizationEnabled)), self.localizationWindowSize, frames_mode, _stream()), 'gccnmf_rt_process_block')
+            int(bool(self.localizationEnabled)), self.localizationWindowSize, frames_mode, int(self.numHUpdates), int(out_delay_blocks),
+            _stream()), 'gccnmf_rt_process_block_ll')
 
     @_on_device
     def processFrames(self, windowedSamples):
@@ -115,7 +145,9 @@ class GCCNMFProcessor(object):
     def intermediates(self):
         F, K, D = self.numFrequencies, self.numAtom, self.numTDOAs
         return dict(X=torch.view_as_complex(self.dX).cpu().numpy(), C=torch.view_as_complex(self.dC).cpu().numpy(),
-                    HMask=self.dHMask[:K].cpu().numpy(), argmaxTDOA=self.dArgmax[:K].cpu().numpy(), tfMask=self.dTfMask.cpu().numpy(),
+                    HMask=self.dHMask[:K].cpu().numpy(), argmaxTDOA=self.dArgmax[:K].cpu().numpy(),
+                    tfMask=(self.dTfMask.cpu().numpy() if self.numHUpdates else self.dTfMask.view(-1)[:F * self.numTimePerChunk].view(F, -1).cpu().numpy()),
+                    Hcoef=self.dHcoef[:K].permute(2, 0, 1).contiguous().cpu().numpy(),
                     gccPHAT=self.dGccPhat.cpu().numpy(), targetTDOAIndex=self.targetTDOAIndex)
 
 
@@ -123,7 +155,11 @@ class StreamingGCCNMF(object):
     """``OverlapAddProcessor.processFrames(GCCNMFProcessor.processFrames)`` (utils.py:99-116) as one device call per block:
     ``process_block((2, blockSize)) -> (2, blockSize)``, output delayed by two blocks like the reference."""
 
-    def __init__(self, processor, hopSize, blockSize):
+    def __init__(self, processor, hopSize, blockSize, outputDelayBlocks=2):
+        # outputDelayBlocks: 2 = the reference's hand-out (utils.py:116); 1 is complete when the synthesis window spans two hops
+        if outputDelayBlocks not in (1, 2, 3, 4, 5, 6, 7):
+            raise ValueError('outputDelayBlocks must be 1..7')
+        self.outputDelayBlocks = int(outputDelayBlocks)
         if blockSize % hopSize or blockSize // hopSize != processor.numTimePerChunk:
             raise ValueError('blockSize/hopSize must equal the processor\'s numTimePerChunk')
         if blockSize > 512 or 8 * blockSize < processor.windowSize + (processor.numTimePerChunk - 1) * hopSize:
@@ -138,7 +174,7 @@ class StreamingGCCNMF(object):
 
     def process_block_device(self, block_in, block_out):
         """Device tensors in/out, asynchronous on the current stream (what a capture/playback loop would call)."""
-        self.p._call(block_in, block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 0)
+        self.p._call(block_in, block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 0, self.outputDelayBlocks)
 
     def process_block(self, block):
         self.block_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))

@@ -192,6 +192,24 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
                             int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
                             int localization_window, int frames_mode, void* stream);
 
+/* Low-latency extension of the call above (BASELINE config 5; README.md:74-78 -- the notebooks that implemented it are not in the
+ * reference checkout, so this part has no reference code to be pinned on):
+ *   synthesis_window [windowSize]  separate synthesis window (asymmetric analysis / synthesis pairs: long analysis window for
+ *                                  spectral resolution, short synthesis window at the end of the frame for latency)
+ *   numHUpdates > 0                per-frame coefficient inference: that many KL-NMF H updates with W fixed
+ *                                  (gccNMFFunctions.py:76), h0 = 1, per channel; the mask becomes W.(h*HMask) / W.h per channel,
+ *                                  tfMask is then [2][F][Tc].  colsumW [Kp] = sum_f W, Hcoef [Kp][2*Tc], Rv [F][2*Tc] scratch.
+ *                                  numHUpdates = 0 is exactly gccnmf_rt_process_block (h = 1).
+ *   out_delay_blocks               which finished block is handed out: 2 = the reference (utils.py:116); 1 is complete when
+ *                                  the synthesis window spans at most two hops */
+int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
+                               float* HMask, int* argmaxTDOA, float* tfMask, float* hist, int* hist_pos, float* target,
+                               float* gccphat, const float* W, const float* cosT, const float* sinT, const float* window,
+                               const float* synthesis_window, const float* twiddle, const float* colsumW, float* Hcoef, float* Rv,
+                               int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp, int numTDOAHistory,
+                               int target_mode, int separation_enabled, int localization_enabled, int localization_window,
+                               int frames_mode, int numHUpdates, int out_delay_blocks, void* stream);
+
 /* Debug: per-workgroup timeline of the LDS-DMA GEMM launches (device buffer of 8 x int64 per workgroup: s_memrealtime
  * [100 MHz] at entry (slots 0 and 1), after the main loop, after the epilogue; [4] = xcc_id<<16 | HW_ID[15:0]).
  * Recorded for launches of at most `blocks` workgroups while buf != NULL (scripts/kbench.py --trace). */

@@ -27,6 +27,23 @@ def make_rt_dictionary(seed, numFrequencies, dictionarySize):
     return (W / np.linalg.norm(W, axis=0)).astype(np.float32)
 
 
+def asymmetric_windows(windowSize, synthesisSize):
+    """PARITY UNPINNED (no reference code: the low-latency notebook of README.md:74-78 is not in the checkout).  Asymmetric analysis /
+    synthesis pair after Mauler & Martin (2007), the construction RT-GCC-NMF's low-latency variant cites: the analysis window rises
+    over windowSize - M samples (half of a long periodic Hann, square-rooted) and falls over the last M = synthesisSize / 2 (half of a
+    short one); the synthesis window lives on the last 2M samples only and is chosen so that analysis * synthesis is the periodic Hann
+    of length 2M -- which overlap-adds to exactly 1 at hop M.  Algorithmic latency 2M samples instead of windowSize."""
+    K, M = int(windowSize), int(synthesisSize) // 2
+    n = np.arange(K, dtype=np.float64)
+    hann = lambda L, m: 0.5 * (1.0 - np.cos(2.0 * np.pi * m / L))
+    long_rise = np.sqrt(hann(2 * (K - M), n))
+    short = hann(2 * M, n - (K - 2 * M))
+    analysis = np.where(n < K - M, long_rise, np.sqrt(np.maximum(short, 0.0)))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        synthesis = np.where(n < K - 2 * M, 0.0, np.where(n < K - M, short / long_rise, np.sqrt(np.maximum(short, 0.0))))
+    return analysis.astype(np.float32), synthesis.astype(np.float32)
+
+
 class CircularHistory(object):
     """gccNMF/realtime/utils.py:34-70 (SharedMemoryCircularBuffer without the shared memory): float64 ring,
     initialised to 0, ``set`` appends along the last axis, ``getUnraveledArray`` returns chronological order."""
@@ -58,7 +75,8 @@ class GCCNMFProcessorOracle(object):
     ``dictionariesW[type][size]`` (:241)."""
 
     def __init__(self, sampleRate, windowSize, numTimePerChunk, W, microphoneSeparationInMetres, numTDOAs,
-                 localizationEnabled=True, localizationWindowSize=6, numTDOAHistory=128, targetMode=TARGET_MODE_WINDOW_FUNCTION):
+                 localizationEnabled=True, localizationWindowSize=6, numTDOAHistory=128, targetMode=TARGET_MODE_WINDOW_FUNCTION,
+                 numHUpdates=0, analysisWindow=None, synthesisWindow=None):
         self.sampleRate, self.windowSize, self.numTimePerChunk = sampleRate, windowSize, numTimePerChunk
         self.W = np.asarray(W, np.float32)
         self.numFrequencies, self.numAtom = self.W.shape
@@ -68,6 +86,11 @@ class GCCNMFProcessorOracle(object):
         self.separationEnabled = True
         self.windowFunction = np.sqrt(np.hamming(windowSize).astype(np.float32))[:, np.newaxis]      # :186
         self.synthesisWindowFunction = self.windowFunction                                           # :187
+        # low-latency extensions (parity unpinned: no reference code): separate windows, per-frame coefficient inference
+        if analysisWindow is not None:
+            self.windowFunction = np.asarray(analysisWindow, np.float32)[:, np.newaxis]
+            self.synthesisWindowFunction = np.asarray(synthesisWindow if synthesisWindow is not None else analysisWindow, np.float32)[:, np.newaxis]
+        self.numHUpdates = int(numHUpdates)
         # :195-198 (initial values; the app then calls setTargetTDOARange with the config's 5.0 / 2.0 / 0.0)
         self.targetTDOAIndex, self.targetTDOAEpsilon = np.float32(10.0), np.float32(2.0)
         self.targetTDOABeta, self.targetTDOANoiseFloor = np.float32(1.0), np.float32(0.0)
@@ -99,10 +122,23 @@ class GCCNMFProcessorOracle(object):
         realGCC = (coherenceV[:, :, np.newaxis] * self.expJOmegaTau[:, np.newaxis]).real             # :254,206 (F, Tc, D)
         if self.separationEnabled:
             HMask, argmaxTDOA = self.coefficientMask(realGCC)                                        # (K, Tc)
-            recSource = np.dot(self.W, HMask)                                                        # :267
-            recV = np.sum(self.W, axis=-1)                                                           # :268
-            tfMask = (recSource.T / recV).T                                                          # :269
-            outputSpectrogram = tfMask * X                                                           # :209
+            if self.numHUpdates == 0:
+                recSource = np.dot(self.W, HMask)                                                    # :267
+                recV = np.sum(self.W, axis=-1)                                                       # :268
+                tfMask = (recSource.T / recV).T                                                      # :269
+                outputSpectrogram = tfMask * X                                                       # :209
+            else:
+                # PARITY UNPINNED: the reference accepts numHUpdates and never uses it (:168).  Coefficient inference = the H update of
+                # gccNMF/gccNMFFunctions.py:76 with W fixed and sparsityAlpha = 0, h0 = 1, per channel and frame on v = |X_c|; with
+                # h = 1 the mask below IS the reference's tfMask, so this generalises it: m_c = W (h_c * HMask) / W h_c.
+                W64 = self.W.astype(np.float64)
+                Hc = np.ones((2, self.numAtom, X.shape[2]))
+                for c in range(2):
+                    v = np.abs(X[c]).astype(np.float64)
+                    for _ in range(self.numHUpdates):
+                        Hc[c] *= np.dot(W64.T, v / np.dot(W64, Hc[c])) / np.sum(W64, axis=0)[:, np.newaxis]
+                tfMask = np.stack([np.dot(W64, Hc[c] * HMask) / np.dot(W64, Hc[c]) for c in range(2)])
+                outputSpectrogram = tfMask * X
         else:
             HMask = argmaxTDOA = tfMask = None
             outputSpectrogram = X.copy()
@@ -123,7 +159,8 @@ class OverlapAddOracle(object):
     buffers, ``windowsPerBlock`` windows cut from the tail of the input buffer, processed frames overlap-added at the same
     positions, and the block that is two blocks old handed out (:116)."""
 
-    def __init__(self, numChannels, windowSize, hopSize, blockSize, windowsPerBlock):
+    def __init__(self, numChannels, windowSize, hopSize, blockSize, windowsPerBlock, outputDelayBlocks=2):
+        self.outputDelayBlocks = int(outputDelayBlocks)      # 2 = the reference (utils.py:116); 1 for short synthesis windows (unpinned)
         self.numChannels, self.windowSize, self.hopSize = numChannels, windowSize, hopSize
         self.blockSize, self.windowsPerBlock = blockSize, windowsPerBlock
         self.numBlocksPerBuffer = 8
@@ -145,7 +182,8 @@ class OverlapAddOracle(object):
         processedFrames = processFramesFunction(self.windowedSamples)
         for i, windowIndex in enumerate(windowIndexes):
             self.outputBuffer[:, windowIndex:windowIndex + self.windowSize] += processedFrames[..., i]
-        return self.outputBuffer[:, -3 * B:-2 * B].copy()
+        d = self.outputDelayBlocks
+        return self.outputBuffer[:, -(d + 1) * B:(-d * B)].copy()
 
 
 def run_stream(stereoSamples, processor, windowSize, hopSize, blockSize):

@@ -153,3 +153,54 @@ def test_stream_vs_reference_goldens(case):
     # worst sample 2.3e-5 at peak 0.1 in the 300-block hop-64 case, where every sample is covered by 8 windows)
     assert worst < 5e-4 * np.abs(x).max(), worst
     assert np.sqrt(sq / (2 * B * compared)) < 3e-5 * np.abs(x).max(), np.sqrt(sq / (2 * B * compared))
+
+
+# ---- low-latency extensions (BASELINE config 5; no reference code exists for them: oracle "parity unpinned") --------------------
+@pytest.mark.parametrize('ws,K,D,Tc,n', [(512, 256, 64, 1, 1), (512, 1024, 64, 1, 3), (256, 96, 33, 4, 2)])
+def test_coefficient_inference_and_asymmetric_windows_match_oracle(ws, K, D, Tc, n):
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, asymmetricWindows
+    a, sy = asymmetricWindows(ws, ws // 4)
+    W = R.make_rt_dictionary(21, ws // 2 + 1, K)
+    dev = GCCNMFProcessor(16000, ws, Tc, {'Pretrained': {K: W}}, 'Pretrained', K, n, 0.1, False, 6, numTDOAs=D, analysisWindow=a,
+                          synthesisWindow=sy)
+    ora = R.GCCNMFProcessorOracle(16000, ws, Tc, W, 0.1, D, localizationEnabled=False, numHUpdates=n, analysisWindow=a, synthesisWindow=sy)
+    rng = np.random.RandomState(8)
+    for params in [(9.6, 5.0, 2.0, 0.0), (20.0, 3.0, 1.0, 0.2)]:
+        dev.setTargetTDOARange(*params)
+        ora.setTargetTDOARange(*params)
+        frames = (rng.standard_normal((2, ws, Tc)) * 0.1).astype(np.float32)
+        out = dev.processFrames(frames)
+        ref, im = ora.processFrames(frames, return_intermediates=True)
+        d = dev.intermediates()
+        assert np.abs(d['X'] - im['X']).max() < 1e-5 * np.abs(im['X']).max()
+        same = d['argmaxTDOA'] == im['argmaxTDOA']
+        assert same.mean() > 0.995
+        if same.all():
+            assert d['tfMask'].shape == (2, ws // 2 + 1, Tc)
+            assert np.abs(d['tfMask'] - im['tfMask']).max() < 2e-4
+            assert np.abs(out - ref).max() < 2e-4 * np.abs(ref).max()
+
+
+def test_low_latency_stream_is_the_identity_one_block_late_when_separation_is_off():
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF, asymmetricWindows
+    ws, hop, K, D = 512, 64, 64, 32
+    a, sy = asymmetricWindows(ws, 2 * hop)
+    W = R.make_rt_dictionary(2, ws // 2 + 1, K)
+    dev = GCCNMFProcessor(16000, ws, 1, {'Pretrained': {K: W}}, 'Pretrained', K, 2, 0.1, False, 6, numTDOAs=D, analysisWindow=a, synthesisWindow=sy)
+    dev.separationEnabled = False
+    x = (np.random.RandomState(4).standard_normal((2, 60 * hop)) * 0.05).astype(np.float32)
+    y = StreamingGCCNMF(dev, hop, hop, outputDelayBlocks=1).process_stream(x)
+    assert np.abs(y[:, 9 * hop:] - x[:, 8 * hop:-hop]).max() < 1e-5
+    # and with separation on: the device stream against the oracle stream, same windows, delay and coefficient updates
+    dev.separationEnabled = True
+    dev.reset()
+    dev.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    ora = R.GCCNMFProcessorOracle(16000, ws, 1, W, 0.1, D, localizationEnabled=False, numHUpdates=2, analysisWindow=a, synthesisWindow=sy)
+    ora.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    ola = R.OverlapAddOracle(2, ws, hop, hop, 1, outputDelayBlocks=1)
+    xs = O.synthetic_mixture(6, numSamples=60 * hop, delays=(-3, 1, 4))
+    yd = StreamingGCCNMF(dev, hop, hop, outputDelayBlocks=1).process_stream(xs)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        yr = np.concatenate([ola.processFrames(xs[:, b * hop:(b + 1) * hop], ora.processFrames) for b in range(60)], axis=1)
+    assert np.abs(yd - yr).max() < 5e-4 * np.abs(xs).max()

@@ -76,3 +76,55 @@ def test_silence_does_not_produce_nan_audio():
             out, im = p.processFrames(np.zeros((2, ws, 1), np.float32), return_intermediates=True)
     assert np.isfinite(out).all() and not out.any()
     assert np.isnan(im['gccPHAT']).all() and (im['argmaxTDOA'] == 0).all()
+
+
+def test_asymmetric_windows_reconstruct_at_low_latency():
+    """(parity unpinned extension) analysis * synthesis = periodic Hann on the last 2M samples, zero before; overlap-add at hop M is the
+    identity, complete ONE block after the newest sample; the product's helper builds the same pair."""
+    K, S = 512, 128
+    a, sy = R.asymmetric_windows(K, S)
+    M = S // 2
+    prod = a.astype(np.float64) * sy
+    assert not prod[:K - S].any()
+    assert np.allclose(prod[K - S:], 0.5 * (1 - np.cos(2 * np.pi * np.arange(S) / S)), atol=1e-6)
+    assert np.allclose(prod[K - S:K - M] + prod[K - M:], 1.0, atol=1e-6)                  # COLA at hop M
+    assert a.max() <= 1.0 + 1e-6 and a[K - M - 1] > 0.99 and np.isfinite(sy).all()
+    from gcc_nmf_amd.realtime import asymmetricWindows
+    pa, ps = asymmetricWindows(K, S)
+    assert np.array_equal(pa, a) and np.array_equal(ps, sy)
+    ola = R.OverlapAddOracle(2, K, M, M, 1, outputDelayBlocks=1)
+    rng = np.random.RandomState(3)
+    x = rng.standard_normal((2, 40 * M)).astype(np.float32)
+    win = (a * sy)[None, :, None]
+    y = np.concatenate([ola.processFrames(x[:, b * M:(b + 1) * M], lambda w: w * win) for b in range(40)], axis=1)
+    assert np.allclose(y[:, 9 * M:], x[:, 8 * M:-M], atol=1e-5)                          # input, one block late
+
+
+def test_coefficient_inference_generalises_the_reference_mask():
+    """(parity unpinned extension) numHUpdates = 0 is the reference's mask; every H update lowers the KL divergence D(|X| || W h)."""
+    rng = np.random.RandomState(5)
+    ws, K, D, Tc = 128, 24, 16, 3
+    W = R.make_rt_dictionary(9, ws // 2 + 1, K)
+    frames = rng.standard_normal((2, ws, Tc)).astype(np.float32)
+    outs = []
+    for n in (0, 1, 4):
+        p = R.GCCNMFProcessorOracle(16000, ws, Tc, W, 0.1, D, localizationEnabled=False, numHUpdates=n)
+        p.setTargetTDOARange(5.0, 3.0, 2.0, 0.05)
+        y, im = p.processFrames(frames, return_intermediates=True)
+        outs.append((y, im))
+    assert outs[0][1]['tfMask'].shape == (ws // 2 + 1, Tc) and outs[1][1]['tfMask'].shape == (2, ws // 2 + 1, Tc)
+    assert np.all(outs[2][1]['tfMask'] >= 0) and np.all(outs[2][1]['tfMask'] <= outs[2][1]['HMask'].max() + 1e-9)    # a convex mix of HMask
+    X = outs[0][1]['X']
+    W64 = W.astype(np.float64)
+
+    def kl(h, v):
+        wh = W64 @ h
+        return float(np.sum(v * np.log(v / wh) - v + wh))
+    v = np.abs(X[0]).astype(np.float64)
+    h = np.ones((K, Tc))
+    prev = kl(h, v)
+    for _ in range(4):
+        h *= (W64.T @ (v / (W64 @ h))) / W64.sum(0)[:, None]
+        cur = kl(h, v)
+        assert cur < prev
+        prev = cur
