@@ -88,15 +88,33 @@ def performKLNMF(V, dictionarySize, numIterations, sparsityAlpha, epsilon=1e-16,
     W = random((F, K)).astype(float32) + epsilon
     H = random((K, N)).astype(float32) + epsilon
     lib, dev = _hip.lib(), _device()
-    g = Geometry(F, 1, K)
-    Np = -(-N // 64) * 64
-    dV = padded(V.astype(float32), (g.Fp, Np), dev)
-    dW = padded(W.astype(float32), (g.Fp, g.Kp), dev)
-    dH = padded(H.astype(float32), (g.Kp, Np), dev)
-    ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, 1), dtype=torch.float32, device=dev)
-    _hip.check(lib.gccnmf_klnmf(_ptr(dV), _ptr(dW), _ptr(dH), _ptr(ws), F, N, K, 1, int(numIterations),
+    b = _klnmf_buffers(F, N, K, dev)
+    g = b['g']
+    # the padding of the cached buffers is zero and stays zero (the kernels never write it): only the F x N / F x K / K x N
+    # corners are re-uploaded -- no allocation, no zero fill, no workspace set-up per call
+    b['V'][:F, :N].copy_(torch.from_numpy(np.ascontiguousarray(V, dtype=float32)))
+    b['W'][:F, :K].copy_(torch.from_numpy(W.astype(float32)))
+    b['H'][:K, :N].copy_(torch.from_numpy(H.astype(float32)))
+    _hip.check(lib.gccnmf_klnmf(_ptr(b['V']), _ptr(b['W']), _ptr(b['H']), _ptr(b['ws']), F, N, K, 1, int(numIterations),
                                 float(sparsityAlpha), float(epsilon), 0, _stream()), 'gccnmf_klnmf')
-    return dW[:F, :K].cpu().numpy(), dH[:K, :N].cpu().numpy()
+    return b['W'][:F, :K].cpu().numpy(), b['H'][:K, :N].cpu().numpy()
+
+
+_KLNMF_BUFFERS = {}          # (F, N, K, device) -> padded device buffers + workspace, a few most recent shapes
+
+
+def _klnmf_buffers(F, N, K, dev):
+    key = (F, N, K, str(dev))
+    b = _KLNMF_BUFFERS.pop(key, None)
+    if b is None:
+        g = Geometry(F, 1, K)
+        Np = -(-N // 64) * 64
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        b = dict(g=g, V=z(g.Fp, Np), W=z(g.Fp, g.Kp), H=z(g.Kp, Np), ws=z(_hip.lib().gccnmf_klnmf_workspace_floats(F, N, K, 1)))
+    _KLNMF_BUFFERS[key] = b                      # most recently used last
+    while len(_KLNMF_BUFFERS) > 4:
+        _KLNMF_BUFFERS.pop(next(iter(_KLNMF_BUFFERS)))
+    return b
 
 
 def _upload_coherence(C, g, dev):
