@@ -46,6 +46,7 @@ def parse():
                         'whole batch, the configuration the roofline kernel is timed in')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
+    p.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='gccnmf_set_tuning(KEY, VALUE) before running (A/B experiments)')
     p.add_argument('--h-updates', type=int, default=2, help='streaming mode: KL-NMF coefficient updates per frame (W fixed)')
     p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming'], default='separate',
                    help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4; 'streaming' = config 5")
@@ -251,6 +252,10 @@ def main():
 
     from gcc_nmf_amd.engine import GCCNMFEngine
     from gcc_nmf_amd.synthetic import synthetic_batch
+    for kv in a.tune:
+        from gcc_nmf_amd import _hip
+        key, val = [int(v) for v in kv.split('=')]
+        _hip.check(_hip.lib().gccnmf_set_tuning(key, val), 'gccnmf_set_tuning')
 
     sr = 16000
     n = int(a.seconds * sr)
