@@ -154,3 +154,151 @@ def train_shared_dictionary(local, numIterations, group=None):
         local.step_b(partial)
     local.finish()
     return local
+
+
+# ---- 3. one LONG mixture, sharded over frame windows ------------------------------------------------------------------------
+# north_star: "sharding ... frame windows with RCCL all-reduce over xGMI only for the shared-dictionary W update".  Ranks own contiguous
+# frame ranges of ONE mixture.  Per rank: STFT of its own sample range; KL-NMF with W replicated (mode 2: one all-reduce of [num || den]
+# per iteration); the time mean of the angular spectrum (runGCCNMF.py:46) is a second, tiny all-reduce (D float64, once) so that every
+# rank picks the same target TDOAs; scores, masks and spectrogram estimates are frame-local; the overlap-add (librosaSTFT.py:275-284)
+# of a rank's first n_fft - hop samples also needs the previous rank's last n_fft/hop - 1 FRAMES: they are exchanged as frames, not as
+# partial sums, and added in ascending frame order, so the stitched waveform is bit-identical to the single-rank one wherever the
+# factors are.
+def shard_frames(num_frames, world_size, rank):
+    """Contiguous, balanced frame range [t0, t1) of ``rank``."""
+    if not 0 <= rank < world_size:
+        raise ValueError('rank %d outside world of %d' % (rank, world_size))
+    q, r = divmod(num_frames, world_size)
+    t0 = rank * q + min(rank, r)
+    return t0, t0 + q + (1 if rank < r else 0)
+
+
+def time_shard_initial_factors(F, T, K, t0, t1, epsilon=1e-16, seedValue=0):
+    """performKLNMF's initial factors (gccNMFFunctions.py:70-73: one MT19937 stream, W first, then H (K, 2T) over the columns
+    [left frames | right frames]) restricted to the frames [t0, t1): W (F, K) and H (K, 2*(t1-t0)) in the same [left | right] order."""
+    rs = np.random.RandomState(seedValue)
+    W = rs.random_sample((F, K)).astype(np.float32) + epsilon
+    H = rs.random_sample((K, 2 * T)).astype(np.float32) + epsilon
+    Hl = np.concatenate([H[:, t0:t1], H[:, T + t0:T + t1]], axis=1)
+    return W.astype(np.float32), np.ascontiguousarray(Hl).astype(np.float32)
+
+
+def separate_time_sharded(local, numIterations, group=None):
+    """The frame-sharded separation, identical on every rank.  ``local`` owns this rank's frames [t0, t1) of a T-frame mixture and
+    provides:  stft();  nmf (begin/step_a/step_b/finish as in mode 2);  nmf_done();  angular_sum() -> float64 tensor (D,) = sum over
+    own frames;  set_angular_mean(mean) (picks the target TDOAs);  masks_and_spectrograms();  tail_frames() -> tensor (nsig, halo,
+    n_fft);  overlap_add(previous_tail or None) -> (segment (S, 2, len) ndarray, first global sample index of the TRIMMED output).
+    Returns (segment, start).  Collectives: numIterations all-reduces of F*K + K floats, one of D doubles, one all-gather of the
+    halo frames (nsig * halo * n_fft floats per rank)."""
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if distributed else 0
+    local.stft()
+    train_shared_dictionary(local.nmf, numIterations, group)
+    local.nmf_done()
+    s = local.angular_sum()
+    if distributed:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    local.set_angular_mean(s / float(local.T_total))
+    local.masks_and_spectrograms()
+    tail = local.tail_frames()
+    previous = None
+    if distributed:
+        tails = [torch.empty_like(tail) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(tails, tail, group=group)
+        if rank > 0:
+            previous = tails[rank - 1]
+    return local.overlap_add(previous)
+
+
+def stitch_time_shards(segments, numTargets, total_frames, hop):
+    """[(segment (S, 2, len), start)] of every rank -> (S, 2, hop*(T-1)) like getTargetSignalEstimates on the whole mixture."""
+    L = hop * (total_frames - 1)
+    y = np.zeros((numTargets, 2, L), np.float32)
+    for seg, start in segments:
+        lo, hi = max(start, 0), min(start + seg.shape[2], L)
+        if hi > lo:
+            y[:, :, lo:hi] = seg[:, :, lo - start:hi - start]
+    return y
+
+
+class HipTimeShard(object):
+    """This rank's frames [t0, t1) of one long mixture on the GPU: a batch-1 ``GCCNMFEngine`` over the rank's sample range plus a
+    ``HipSharedNMF`` on its magnitude spectrogram.  ``stereoSamples`` is the WHOLE (2, n) mixture (only the own range is uploaded)."""
+
+    def __init__(self, stereoSamples, rank, world_size, sampleRate=16000, windowSize=1024, hopSize=256, numTDOAs=128,
+                 microphoneSeparationInMetres=1.0, numTargets=3, dictionarySize=128, sparsityAlpha=0, epsilon=1e-16, seedValue=0,
+                 device=None):
+        from .engine import GCCNMFEngine, num_frames
+        x = np.asarray(stereoSamples, np.float32)
+        self.n_fft, self.hop, self.S = int(windowSize), int(hopSize), int(numTargets)
+        self.T_total = num_frames(x.shape[1], self.n_fft, self.hop)
+        self.halo = -(-self.n_fft // self.hop) - 1
+        self.t0, self.t1 = shard_frames(self.T_total, world_size, rank)
+        self.last = rank == world_size - 1
+        Tr = self.t1 - self.t0
+        if Tr < max(self.halo, 2):
+            raise ValueError('time shard of %d frames is shorter than the overlap-add halo (%d frames)' % (Tr, self.halo))
+        lo, hi = self.t0 * self.hop, (self.t1 - 1) * self.hop + self.n_fft
+        dev = device if device is not None else 'cuda:%d' % torch.cuda.current_device()
+        self.e = e = GCCNMFEngine(hi - lo, sampleRate=sampleRate, windowSize=windowSize, hopSize=hopSize, numTDOAs=numTDOAs,
+                                  microphoneSeparationInMetres=microphoneSeparationInMetres, numTargets=numTargets,
+                                  dictionarySize=dictionarySize, numIterations=0, sparsityAlpha=sparsityAlpha, epsilon=epsilon, batch=1,
+                                  device=dev)
+        assert e.g.T == Tr
+        self.device = e.device
+        e.upload(x[:, lo:hi])
+        self._W0, self._H0 = time_shard_initial_factors(e.g.F, self.T_total, e.g.K, self.t0, self.t1, epsilon, seedValue)
+        self._alpha, self._eps = sparsityAlpha, epsilon
+        self.nmf = None
+
+    @_on_device
+    def stft(self):
+        e = self.e
+        e.stft()
+        self.nmf = HipSharedNMF.from_device(e.V, e.g.F, e.g.N, self._W0, [self._H0], self._alpha, self._eps)
+
+    @_on_device
+    def nmf_done(self):
+        self.e.W[0].copy_(self.nmf.Wd)
+        self.e.H[0].copy_(self.nmf.Hd[0])
+
+    @_on_device
+    def angular_sum(self):
+        e, g = self.e, self.e.g
+        _hip.check(e.lib.gccnmf_angular_spectrogram(_ptr(e.CC), _ptr(e.trig), g.F, g.T, g.D, 1, _ptr(e.ang), _ptr(e.mean_ang), _stream()),
+                   'gccnmf_angular_spectrogram')
+        return e.mean_ang[0, :g.D] * float(g.T)                  # float64: mean over own frames * own frames
+
+    @_on_device
+    def set_angular_mean(self, mean):
+        e, g = self.e, self.e.g
+        e.mean_ang[0, :g.D].copy_(mean.to(e.mean_ang.device))
+        _hip.check(e.lib.gccnmf_pick_tdoa_peaks(_ptr(e.mean_ang), g.D, g.Dp, g.S, 1, _ptr(e.tdoa_idx), _ptr(e.status), _stream()),
+                   'gccnmf_pick_tdoa_peaks')
+        e.check_status()
+
+    @_on_device
+    def masks_and_spectrograms(self):
+        self.e.masks()
+        self.e.reconstruct()
+        self.e.istft()                                           # windowed time frames of the own spectrogram estimates -> e.frames
+
+    @_on_device
+    def tail_frames(self):
+        return self.e.frames[0, :, self.e.g.T - self.halo:, :].contiguous()
+
+    @_on_device
+    def overlap_add(self, previous):
+        e, g = self.e, self.e.g
+        nsig = 2 * g.S
+        prev = previous.to(self.device) if previous is not None else torch.zeros((nsig, self.halo, self.n_fft), dtype=torch.float32, device=self.device)
+        frames = torch.cat([prev, e.frames[0]], dim=1).contiguous()                      # [nsig][halo + T_r][n_fft], ascending frames
+        L = (g.T - 1) * self.hop + self.n_fft if self.last else g.T * self.hop           # the samples this rank owns
+        y = torch.zeros((nsig, L), dtype=torch.float32, device=self.device)
+        gain = np.float32(self.hop / float(self.n_fft) * 2)                              # gccNMFFunctions.py:155
+        _hip.check(e.lib.gccnmf_ola_frames(_ptr(frames), nsig, self.n_fft, self.hop, self.halo + g.T, 1, self.halo * self.hop, L, gain,
+                                           _ptr(y), _stream()), 'gccnmf_ola_frames')
+        return y.view(g.S, 2, L).cpu().numpy(), self.t0 * self.hop - self.n_fft // 2    # centre trim (librosaSTFT.py:283-284)
+
+    def tdoa_indexes(self):
+        return self.e.get_tdoa_indexes()[0]

@@ -167,6 +167,13 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
 
+/* The overlap-add half of the call above on its own: frames [batch][nsig][T][n_fft] (windowed time frames, e.g. a neighbour
+ * shard's last frames followed by this shard's own) -> y [batch][nsig][L] = samples first_sample .. first_sample+L-1 of the
+ * overlap-added stream, frames added in ascending order (librosaSTFT.py:275-281), times gain.  Used by the time-sharded
+ * single-mixture mode, where a shard's first samples need the previous shard's last n_fft/hop - 1 frames. */
+int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, int batch, int first_sample, int L, float gain,
+                      float* y, void* stream);
+
 /* Streaming (real-time) GCC-NMF: one block of `blockSize` new stereo samples per call, Tc = blockSize/hopSize analysis
  * windows.  Replaces GCCNMFProcessor.processFrames (gccNMF/realtime/gccNMFProcessor.py:201-270, a Theano graph in the
  * reference) together with OverlapAddProcessor.processFrames (gccNMF/realtime/utils.py:99-116) and the gccPHAT history /

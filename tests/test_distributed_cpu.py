@@ -91,3 +91,72 @@ def test_per_file_initialisation_is_world_size_independent():
             assert np.array_equal(Wa, Wb)
             for j, i in enumerate(mine):
                 assert np.array_equal(Ha[i], Hb[j])
+
+
+# ---- mode 3: one long mixture sharded over frame windows ---------------------------------------------------------------------
+def _long_mixture():
+    from oracle import gccnmf_oracle as O
+    return O.synthetic_mixture(11, numSamples=24000)          # 90 frames at hop 256
+
+
+def test_shard_frames_and_initial_factors():
+    from gcc_nmf_amd.distributed import shard_frames, time_shard_initial_factors
+    for T, w in [(90, 2), (622, 8), (7, 3)]:
+        r = [shard_frames(T, w, k) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == T and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    rs = np.random.RandomState(0)
+    W = rs.random_sample((5, 3)).astype(np.float32)
+    H = rs.random_sample((3, 20)).astype(np.float32)
+    W0, H0 = time_shard_initial_factors(5, 10, 3, 4, 7, epsilon=0)
+    assert np.array_equal(W0, W) and np.array_equal(H0, np.concatenate([H[:, 4:7], H[:, 14:17]], axis=1))
+
+
+def test_time_sharded_single_rank_is_the_reference_pipeline():
+    """One shard holding every frame == oracle.runGCCNMF (gccNMF/runGCCNMF.py:36-52) on the whole mixture."""
+    from gcc_nmf_amd.distributed import separate_time_sharded, stitch_time_shards
+    from oracle.time_shard_oracle import NumpyTimeShard
+    from oracle import gccnmf_oracle as O
+    x = _long_mixture()
+    local = NumpyTimeShard(x, 0, 1, dictionarySize=16)
+    seg = separate_time_sharded(local, 10)
+    y = stitch_time_shards([seg], 3, local.T_total, 256)
+    r = O.runGCCNMF(x, 16000, 1024, 256, 128, 1.0, 3, dictionarySize=16, numIterations=10, return_intermediates=True)
+    assert local.idx == r['idx'] and y.shape == r['y'].shape
+    assert np.abs(y - r['y']).max() < 1e-5 * np.abs(r['y']).max()
+
+
+def _time_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    from gcc_nmf_amd.distributed import separate_time_sharded
+    from oracle.time_shard_oracle import NumpyTimeShard
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    try:
+        local = NumpyTimeShard(_long_mixture(), rank, world, dictionarySize=16)
+        seg, start = separate_time_sharded(local, 10)
+        np.savez(os.path.join(out_dir, 'time_rank%d.npz' % rank), seg=seg, start=start, idx=np.array(local.idx), W=local.W, T=local.T_total)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_time_sharded_two_ranks_gloo(tmp_path):
+    """Two processes, each with half of the frames: W all-reduce per iteration, one all-reduce of the angular spectrum, halo frames
+    all-gathered; the stitched waveform equals the single-shard one up to the summation order of the two collectives."""
+    from gcc_nmf_amd.distributed import separate_time_sharded, stitch_time_shards
+    from oracle.time_shard_oracle import NumpyTimeShard
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_time_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / ('time_rank%d.npz' % k)) for k in range(2)]
+    assert np.array_equal(r[0]['W'], r[1]['W']) and r[0]['idx'].tolist() == r[1]['idx'].tolist()
+    T = int(r[0]['T'])
+    y2 = stitch_time_shards([(r[k]['seg'], int(r[k]['start'])) for k in range(2)], 3, T, 256)
+    one = NumpyTimeShard(_long_mixture(), 0, 1, dictionarySize=16)
+    y1 = stitch_time_shards([separate_time_sharded(one, 10)], 3, T, 256)
+    assert one.idx == r[0]['idx'].tolist()
+    assert int(r[0]['start']) + r[0]['seg'].shape[2] == int(r[1]['start'])          # the segments tile the output
+    assert np.abs(y2 - y1).max() < 1e-5 * np.abs(y1).max()
+    assert np.sqrt(np.mean((y2 - y1) ** 2)) < 1e-6
