@@ -48,8 +48,8 @@ def parse():
     p.add_argument('--skip-cpu-baseline', action='store_true')
     p.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='gccnmf_set_tuning(KEY, VALUE) before running (A/B experiments)')
     p.add_argument('--h-updates', type=int, default=2, help='streaming mode: KL-NMF coefficient updates per frame (W fixed)')
-    p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming'], default='separate',
-                   help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4; 'streaming' = config 5")
+    p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming', 'time-sharded'], default='separate',
+                   help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4; 'streaming' = config 5; 'time-sharded' = ONE long mixture (--seconds, default 160 s there) sharded over frame windows, strong scaling")
     return p.parse_args()
 
 
@@ -135,6 +135,53 @@ def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_see
             'dictionary_finite_unit_norm': bool(np.isfinite(W).all() and np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-4)),
         }))
     if world > 1:
+        dist.destroy_process_group()
+
+
+def time_sharded_mode(a, world, rank, local_rank, barrier, ranks_seen, backend):
+    """ONE long mixture, frame windows sharded over the ranks (north_star's second partitioning): W all-reduce per iteration, one
+    all-reduce of the angular spectrum, halo frames all-gathered for the overlap-add seam.  Strong scaling: total work is fixed."""
+    import torch
+    import torch.distributed as dist
+    from gcc_nmf_amd.distributed import HipTimeShard, separate_time_sharded
+    from gcc_nmf_amd.synthetic import synthetic_mixture
+    sr = 16000
+    seconds = a.seconds if a.seconds != 10.0 else 160.0
+    x = synthetic_mixture(7, numSamples=int(seconds * sr), sampleRate=sr)
+    local = HipTimeShard(x, rank, world, sampleRate=sr, hopSize=a.hop, dictionarySize=a.dictionary_size, device='cuda:%d' % local_rank)
+
+    def step():
+        return separate_time_sharded(local, a.iterations)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        seg, start = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'stereo frames/sec, ONE %.0f s mixture sharded over frame windows (1024-FFT, K=%d, %d NMF iters)' % (seconds, a.dictionary_size, a.iterations),
+            'value': local.T_total * a.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'one %.0f s stereo mixture (%d frames), host samples in -> host waveform segments out; frames sharded x%d, '
+                                   'W replicated: %d all-reduces of F*K+K floats, 1 of 128 doubles, 1 all-gather of 3 halo frames per signal'
+                                   % (seconds, local.T_total, world, a.iterations), 'frames': local.T_total, 'dictionary_size': a.dictionary_size,
+                       'nmf_iterations': a.iterations, 'parallelism': 'frame windows sharded x%d' % world},
+            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None,
+            'tdoa_indexes': local.tdoa_indexes().tolist(), 'segment_finite': bool(np.isfinite(seg).all())}))
+    if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 
@@ -250,6 +297,16 @@ def main():
         if ranks_seen != a.gpus:
             raise SystemExit('bench.py: %d ranks answered the all-reduce, --gpus %d' % (ranks_seen, a.gpus))
 
+    def barrier():
+        if world > 1:
+            if backend == 'nccl':
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+
+    if a.mode == 'time-sharded':
+        return time_sharded_mode(a, world, rank, local_rank, barrier, ranks_seen, backend)
+
     from gcc_nmf_amd.engine import GCCNMFEngine
     from gcc_nmf_amd.synthetic import synthetic_batch
     for kv in a.tune:
@@ -266,13 +323,6 @@ def main():
                      klnmf_flags=1 if a.no_xcd_affinity else 0, nmf_groups=a.nmf_groups)
     g = e.g
     e.upload(xs)                                                             # inputs resident in HBM before timing
-
-    def barrier():
-        if world > 1:
-            if backend == 'nccl':
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
 
     if a.mode == 'shared-dictionary':
         return shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen, backend)

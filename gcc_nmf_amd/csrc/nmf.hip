@@ -361,7 +361,7 @@ static bool small_batch_tile(const GemmArgs& a) {
 template <bool A_KC, bool B_KC, int EPI>
 static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
     const bool tall = a.M > 128;
-    if (small_batch_tile(a) && gccnmf_tune_ring) {
+    if (small_batch_tile(a) && gccnmf_tune_ring && gccnmf_ring_supports(a.Kd)) {   // (longer reductions: the register-staged tile below)
         if (A_KC) return tail ? gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);
         if (tail) return GCCNMF_ERR_ARG;
         return gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);
@@ -528,7 +528,7 @@ static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W,
     a.tail_row = g.F - 1;
     a.C = P; a.sC = g.sV; a.ldc = g.Np;
     int rc;
-    if (gccnmf_tune_ring)
+    if (gccnmf_tune_ring && gccnmf_ring_supports(a.Kd))
         rc = g.tail ? gccnmf_launch_gemm_ring<true, false, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_STORE, false>(a, s);
     else
         rc = g.tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false, 1>(a, s);
@@ -551,7 +551,7 @@ static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, fl
     a.tail_row = g.F - 1;
     a.rowsumB = rowsum_part; a.s_rowsumB = g.Kp;
     a.C = Upart; a.sC = g.sU; a.ldc = g.Kp;
-    if (gccnmf_tune_ring)
+    if (gccnmf_tune_ring && gccnmf_ring_supports(a.Kd))
         return g.tail ? gccnmf_launch_gemm_ring<true, true, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, true, EPI_STORE, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }

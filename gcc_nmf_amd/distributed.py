@@ -141,6 +141,38 @@ class HipSharedNMF(object):
         return [h[:self.K, :self.N].cpu().numpy() for h in self.Hd]
 
 
+class CompositeSharedNMF(object):
+    """Several shards of one rank behind the begin / step_a / step_b / finish protocol: their [num || den] partials are added (fixed
+    order) before the all-reduce and every member applies the same reduced buffer.  Lets one rank hold column blocks of different
+    widths (``HipSharedNMF`` needs equal N per object): e.g. the equal blocks of a long mixture plus its ragged remainder."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        self.partial = self.members[0].partial
+
+    def begin(self):
+        for m in self.members:
+            m.begin()
+
+    def step_a(self):
+        parts = [m.step_a() for m in self.members]
+        total = parts[0]
+        for p in parts[1:]:
+            total += p
+        return total
+
+    def step_b(self, partial):
+        for m in self.members:
+            m.step_b(partial)
+
+    def finish(self):
+        for m in self.members:
+            m.finish()
+
+    def W(self):
+        return self.members[0].W()
+
+
 def train_shared_dictionary(local, numIterations, group=None):
     """The shared-dictionary iteration, identical on every rank.  ``local`` owns this rank's columns and provides
     begin() / step_a() -> partial tensor [num (Fp*Kp) || den (Kp)] / step_b(partial) / finish().
@@ -251,16 +283,55 @@ class HipTimeShard(object):
         self._alpha, self._eps = sparsityAlpha, epsilon
         self.nmf = None
 
+    # The rank's 2*T_r NMF columns are handed to the batched kernels as pseudo-files of BLOCK frames ([left | right] columns of those
+    # frames, the layout of one 10 s file) plus one ragged remainder: the per-file launches then fill the chip (a single "file" of
+    # 20 000 columns would leave R.H^T with 16 workgroups of 1 250 k-tiles), and the column partition does not change the update
+    # (gccNMFFunctions.py:76 is column-local, :77 sums over all columns).
+    BLOCK = 640
+
+    def _blocks(self):
+        Tr = self.e.g.T
+        nb, rem = divmod(Tr, self.BLOCK)
+        out = [(j * self.BLOCK, self.BLOCK) for j in range(nb)]
+        if rem:
+            out.append((nb * self.BLOCK, rem))
+        return out                                               # [(first frame, frames)]
+
+    def _gather(self, src, T0, Tb, Np_b, rows):
+        """columns [T0, T0+Tb) of both channel halves of a [rows][Np] matrix -> one [rows][Np_b] block"""
+        Tr = self.e.g.T
+        blk = torch.zeros((rows, Np_b), dtype=torch.float32, device=self.device)
+        blk[:, :Tb] = src[:, T0:T0 + Tb]
+        blk[:, Tb:2 * Tb] = src[:, Tr + T0:Tr + T0 + Tb]
+        return blk
+
     @_on_device
     def stft(self):
-        e = self.e
+        e, g = self.e, self.e.g
         e.stft()
-        self.nmf = HipSharedNMF.from_device(e.V, e.g.F, e.g.N, self._W0, [self._H0], self._alpha, self._eps)
+        H0 = torch.zeros((g.Kp, g.Np), dtype=torch.float32, device=self.device)
+        H0[:g.K, :g.N] = torch.from_numpy(self._H0).to(self.device)
+        members, self._groups = [], []
+        blocks = self._blocks()
+        for width in sorted(set(tb for _, tb in blocks), reverse=True):
+            mine = [(t0, tb) for t0, tb in blocks if tb == width]
+            Np_b = -(-2 * width // 64) * 64
+            V = torch.stack([self._gather(e.V[0], t0, tb, Np_b, g.Fp) for t0, tb in mine])
+            shard = HipSharedNMF.from_device(V, g.F, 2 * width, self._W0, [np.zeros((g.K, 2 * width), np.float32)] * len(mine), self._alpha, self._eps)
+            shard.Hd.copy_(torch.stack([self._gather(H0, t0, tb, Np_b, g.Kp) for t0, tb in mine]))
+            shard._H0d = shard.Hd.clone()
+            members.append(shard)
+            self._groups.append(mine)
+        self.nmf = CompositeSharedNMF(members)
 
     @_on_device
     def nmf_done(self):
-        self.e.W[0].copy_(self.nmf.Wd)
-        self.e.H[0].copy_(self.nmf.Hd[0])
+        e, Tr = self.e, self.e.g.T
+        e.W[0].copy_(self.nmf.members[0].Wd)
+        for shard, mine in zip(self.nmf.members, self._groups):
+            for j, (t0, tb) in enumerate(mine):
+                e.H[0][:, t0:t0 + tb] = shard.Hd[j][:, :tb]
+                e.H[0][:, Tr + t0:Tr + t0 + tb] = shard.Hd[j][:, tb:2 * tb]
 
     @_on_device
     def angular_sum(self):
