@@ -60,6 +60,7 @@ struct GemmArgs {
     int M, N, Kd;              // MFMA output rows, output columns, reduction length
     int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
     int tiles_m, tiles_n, batch, xcd_affine;
+    int kparts;                // ring kernel only: > 0 = the `batch` "files" are kparts balanced parts of ONE reduction of Kd (split-K, partial outputs sC apart)
     int ablate;                // timing experiments: 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row, 16 no epilogue (results invalid)
     const float* bscale;       // optional per-reduction-index scale applied to B while staging (non-KC B only)
     long s_bscale;

@@ -56,12 +56,22 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
         p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
         p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
     }
-    const float* __restrict__ A = p.A + file * p.sA;
-    const float* __restrict__ B = p.B + file * p.sB;
-    const float* __restrict__ bscale = (SCALE && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
+    // split-K (kparts > 0): "file" is the part index; all parts read the same operands, each its own balanced range of k-tiles
+    // [kb, kb + nkt) (the first (total % kparts) parts take one more), and writes its own partial output (C + part * sC)
+    const bool split = p.kparts > 0;
+    int kb = 0, nkt = (p.Kd + BK - 1) / BK;
+    if (split) {
+        const int q = nkt / p.kparts, r = nkt - q * p.kparts;
+        kb = file * q + min(file, r);
+        nkt = q + (file < r ? 1 : 0);
+    }
+    kb = __builtin_amdgcn_readfirstlane(kb);
+    nkt = __builtin_amdgcn_readfirstlane(nkt);
+    const float* __restrict__ A = p.A + (split ? 0 : file * p.sA) + (A_KC ? (long)kb * BK : (long)kb * BK * p.lda);
+    const float* __restrict__ B = p.B + (split ? 0 : file * p.sB) + (B_KC ? (long)kb * BK : (long)kb * BK * p.ldb);
+    const float* __restrict__ bscale = (SCALE && p.bscale) ? p.bscale + (split ? 0 : file * p.s_bscale) + kb * BK : nullptr;
     const bool side_wg = (tm == 0);                                // the row-0 workgroups carry the tail row and the row sums
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr) && side_wg;
-    const int nkt = (p.Kd + BK - 1) / BK;
     const int nside = (nkt * BK + 255) & ~255;                     // floats per reduction-index vector in LDS (whole 1 KB pieces)
 
     // per-lane source byte offsets of this wave's pieces: 2 of A (pieces 2w, 2w+1 of 8), 1 of B (piece w of 4)
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
         const unsigned last = 4u * (unsigned)(nkt * BK - 4);
         if (TAIL) {
             if (side_wg) {
-                const float* __restrict__ tail_src = A + (long)p.tail_row * p.lda;
+                const float* __restrict__ tail_src = A + (long)p.tail_row * p.lda;      // (A already points at this part's first k-tile)
                 for (int pc = wave; pc * 256 < nkt * BK; pc += 4) gemm_dma16(tail_src, min(1024u * pc + 16u * lane, last), lds_tailrow + 1024u * pc);
             }
         }

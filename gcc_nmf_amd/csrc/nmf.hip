@@ -18,7 +18,7 @@ int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage 
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
 int gccnmf_tune_ring_depth = 0;    // 0 auto (deep ring when the launch fits one workgroup per CU), else 6 / 10
-int gccnmf_tune_wh_splits = 2;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
+int gccnmf_tune_wh_splits = 3;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
 int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
@@ -47,7 +47,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_ring_depth = value;
         return GCCNMF_OK;
     }
-    if ((key == 5 || key == 6) && (value == 1 || value == 2 || value == 4)) {
+    if ((key == 5 || key == 6) && value >= 1 && value <= 4) {
         (key == 5 ? gccnmf_tune_wh_splits : gccnmf_tune_rht_splits) = value;
         return GCCNMF_OK;
     }
@@ -510,25 +510,31 @@ __global__ __launch_bounds__(256) void nmf_div_partials_kernel(const float* __re
 
 // reduction length (padded) worth cutting: at least 8 k-tiles per part
 static bool single_file_split(const NmfGeom& g, int batch, int reduction, int splits) {
+    const bool ring = gccnmf_tune_ring && gccnmf_ring_supports(reduction);        // balances unequal parts itself
     return batch == 1 && splits > 1 && gccnmf_tune_tile_policy != 1 && g.Fm > 128 && reduction >= GCCNMF_SPLITS * 128 &&
-           (reduction / 16) % splits == 0;
+           (ring || (reduction / 16) % splits == 0);
 }
 
 // P_part = W[:, part] . (hscale * H)[part, :]   (EPI_STORE incl. the VALU tail row), then R = V / sum_part P_part
 static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W, const float* H, const float* hscale, float* P, float* R,
                                hipStream_t s) {
     const int nsplit = gccnmf_tune_wh_splits;
-    const int len = g.Kp / nsplit;                           // atoms per part (multiple of 16)
+    const bool ring = gccnmf_tune_ring && gccnmf_ring_supports(g.Kp);
+    const int len = g.Kp / nsplit;                           // atoms per part (multiple of 16) -- equal parts for the register-staged kernel
     GemmArgs a = {};
     a.A = W; a.sA = len; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = (long)len * g.Np; a.ldb = g.Np; a.b_clamp = g.Np - 4;
     a.M = g.Fm; a.N = g.N; a.Kd = len;
     a.batch = nsplit; a.xcd_affine = 0;
     a.bscale = hscale; a.s_bscale = len;
+    if (ring) {                                              // the ring kernel balances the k-tiles itself (parts need not be equal: 3 parts of 64 tiles)
+        a.kparts = nsplit;
+        a.Kd = g.Kp;
+    }
     a.tail_row = g.F - 1;
     a.C = P; a.sC = g.sV; a.ldc = g.Np;
     int rc;
-    if (gccnmf_tune_ring && gccnmf_ring_supports(a.Kd))
+    if (ring)
         rc = g.tail ? gccnmf_launch_gemm_ring<true, false, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_STORE, false>(a, s);
     else
         rc = g.tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, false, EPI_STORE, false, 1>(a, s);
@@ -542,16 +548,21 @@ static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W,
 // U_part = R[:, part] . H[:, part]^T, rowsum_part = sum_{n in part} H   (consumed by nmf_update_w_kernel with nsplit parts)
 static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, float* Upart, float* rowsum_part, hipStream_t s) {
     const int nsplit = gccnmf_tune_rht_splits;
+    const bool ring = gccnmf_tune_ring && gccnmf_ring_supports(g.Np);
     const int len = g.Np / nsplit;                           // columns per part (multiple of 16; beyond N both operands are zero)
     GemmArgs a = {};
     a.A = R; a.sA = len; a.lda = g.Np; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = len; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = len;
     a.batch = nsplit; a.xcd_affine = 0;
+    if (ring) {                                              // balanced k-tile ranges over the N valid columns only (78 tiles, not 80)
+        a.kparts = nsplit;
+        a.Kd = g.N;
+    }
     a.tail_row = g.F - 1;
     a.rowsumB = rowsum_part; a.s_rowsumB = g.Kp;
     a.C = Upart; a.sC = g.sU; a.ldc = g.Kp;
-    if (gccnmf_tune_ring && gccnmf_ring_supports(a.Kd))
+    if (ring)
         return g.tail ? gccnmf_launch_gemm_ring<true, true, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, true, EPI_STORE, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }

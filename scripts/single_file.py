@@ -46,8 +46,8 @@ if '--profile' in sys.argv:
 lib.gccnmf_set_tuning(4, 0)
 y_old = run('register-staged (round 1)')
 lib.gccnmf_set_tuning(4, 1)
-for wh in (1, 2, 4):
-    for rht in (2, 4):
+for wh in (2, 3, 4):
+    for rht in (4,):
         lib.gccnmf_set_tuning(5, wh)
         lib.gccnmf_set_tuning(6, rht)
         y = run('ring, W.H splits %d, R.H^T splits %d' % (wh, rht))
