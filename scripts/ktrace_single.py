@@ -15,7 +15,6 @@ def main():
     ap.add_argument('--K', type=int, default=1024)
     ap.add_argument('--stages', default='1,2,3,4')
     ap.add_argument('--ablate', type=int, default=0)
-    ap.add_argument('--groups', type=int, default=0, help='ring kernel wave groups: 0 auto, 1, 2')
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
@@ -44,7 +43,6 @@ def main():
     torch.cuda.synchronize()
     nblk = 4096
     lib.gccnmf_set_tuning(1, a.ablate)
-    lib.gccnmf_set_tuning(7, a.groups)
     for st in [int(x) for x in a.stages.split(',')]:
         trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
         for s in (1, 2, 3, 4, 5):          # a warm iteration, then the traced stage in sequence
