@@ -7,7 +7,19 @@
 //   reconstruction        S[i,c]    = W (F x K) . (H_c * M_i) (K x T)  * X_c/|X_c|           (:147-151)
 // The three targets / six (target, channel) pairs are concatenated along the GEMM's column axis,
 // so each stage is ONE launch for the whole batch.
-#include "gemm_mfma.h"
+#include "gemm_ring.h"
+
+extern int gccnmf_tune_ring;            // nmf.hip (gccnmf_set_tuning keys 4 and 2)
+extern int gccnmf_tune_tile_policy;
+
+// One-shot GEMMs of a launch that cannot fill the chip with 512 x 64 tiles (one mixture alone: 60 of them) take the small-tile ring
+// kernel (128 x 64, gemm_ring.h): 240 workgroups instead of 60 -- reconstruction 191 -> ~40 us, scores 83 -> ~25 us, angular
+// spectrogram (three 128 x 256 workgroups before) 148 -> ~40 us for one file.
+static bool gcc_small_launch(int batch, int M, int N, int Kd) {
+    if (!gccnmf_tune_ring || !gccnmf_ring_supports(Kd) || gccnmf_tune_tile_policy == 1) return false;
+    if (gccnmf_tune_tile_policy == 2) return true;
+    return (long)batch * gccnmf_ceil_div(M, 512) * gccnmf_ceil_div(N, 64) < 256;
+}
 
 // mean over time of the angular spectrogram, accumulated in double (runGCCNMF.py:46 works on float64).
 // grid = batch * D, 256 threads.
@@ -166,8 +178,10 @@ int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T,
     a.M = D; a.N = T; a.Kd = 2 * p.Fp;
     a.batch = batch; a.xcd_affine = 0;
     a.C = ang; a.sC = (long)Dp * p.Tp; a.ldc = p.Tp;
-    int rc = (D > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
-                       : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
+    int rc;
+    if (gcc_small_launch(batch, a.M, a.N, a.Kd)) rc = gccnmf_launch_gemm_ring<false, false, EPI_STORE, false>(a, s);
+    else rc = (D > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
+                        : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
     if (rc) return rc;
     if (mean_ang) {
         hipLaunchKernelGGL(ang_mean_kernel, dim3(batch * D), dim3(256), 0, s, ang, T, D, Dp, p.Tp, mean_ang);
@@ -215,8 +229,10 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
     }
     a.batch = batch; a.xcd_affine = 1;
     a.C = scores; a.sC = (long)p.Kp * ncol; a.ldc = ncol;
-    int rc = (K > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
-                       : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
+    int rc;
+    if (gcc_small_launch(batch, a.M, a.N, a.Kd)) rc = gccnmf_launch_gemm_ring<false, false, EPI_STORE, false>(a, s);
+    else rc = (K > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
+                        : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
     if (rc) return rc;
     if (argmax) {
         hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 256), p.Kp, batch), dim3(256), 0, s, scores, K, p.Kp, T,
@@ -272,6 +288,8 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
     a.E0 = V; a.sE0 = (long)p.Fp * p.Np;
     a.X = (const float2*)X; a.sX = 2L * p.Fp * p.Tp;
     a.T = T; a.Tp = p.Tp; a.Fp = p.Fp; a.ldv = p.Np;
+    if (gcc_small_launch(batch, a.M, a.N, a.Kd))
+        return tail ? gccnmf_launch_gemm_ring<true, false, EPI_PHASE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_PHASE, false>(a, s);
     const bool tall = a.M > 128;
     if (tall) return tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, true>(a, s)
                           : gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, false>(a, s);
