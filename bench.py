@@ -419,6 +419,17 @@ def main():
                               # different GEMM tile (launch-size dependent) -> different summation grouping, not bitwise equal
                               'waveform_rms_vs_in_batch': float(np.sqrt(np.mean((e1.y[0].cpu().numpy().astype(np.float64) - e.y[0].cpu().numpy()) ** 2)))}
 
+    if rank == 0 and world == 1:
+        # the drop-in route: the reference-named host-array function (NumPy V in -> NumPy W, H out), as runGCCNMF.py calls it
+        from gcc_nmf_amd import gccNMFFunctions as G
+        V0 = e.get_V()[0]
+        G.performKLNMF(V0, K, 2, 0)                                           # allocates the cached device buffers for this shape
+        t1 = time.perf_counter()
+        G.performKLNMF(V0, K, iters, 0)
+        out['dropin_performKLNMF'] = {'ms': 1e3 * (time.perf_counter() - t1), 'frames_per_s': g.T / (time.perf_counter() - t1),
+                                      'what': 'gcc_nmf_amd.gccNMFFunctions.performKLNMF(V (%d, %d) ndarray, %d, %d, 0): host arrays in and out'
+                                              % (g.F, g.N, K, iters)}
+
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline
         try:
