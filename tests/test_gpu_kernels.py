@@ -203,7 +203,8 @@ def tile_policy(hip, request):
 
 
 @pytest.mark.parametrize('F,N,K,iters,alpha', [(513, 90, 128, 12, 0), (513, 201, 192, 6, 0.3), (257, 77, 40, 10, 0), (200, 333, 300, 5, 0),
-                                               (129, 64, 64, 8, 0), (1025, 50, 64, 4, 0)])
+                                               (129, 64, 64, 8, 0), (1025, 50, 64, 4, 0),
+                                               (513, 900, 640, 5, 0)])      # one file: unequal split-K parts (40 k-tiles in 3, 57 in 4)
 def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha, tile_policy):
     from gcc_nmf_amd.gccNMFFunctions import performKLNMF
     rng = np.random.RandomState(F + N + K)
