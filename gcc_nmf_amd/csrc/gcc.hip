@@ -11,6 +11,7 @@
 
 extern int gccnmf_tune_ring;            // nmf.hip (gccnmf_set_tuning keys 4 and 2)
 extern int gccnmf_tune_tile_policy;
+extern int gccnmf_tune_dma;             // key 3: throughput tiles stage their operands by LDS-DMA (gemm_dma.h)
 
 // One-shot GEMMs of a launch that cannot fill the chip with 512 x 64 tiles (one mixture alone: 60 of them) take the small-tile ring
 // kernel (128 x 64, gemm_ring.h): 240 workgroups instead of 60 -- reconstruction 191 -> ~40 us, scores 83 -> ~25 us, angular
@@ -231,6 +232,7 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
     a.C = scores; a.sC = (long)p.Kp * ncol; a.ldc = ncol;
     int rc;
     if (gcc_small_launch(batch, a.M, a.N, a.Kd)) rc = gccnmf_launch_gemm_ring<false, false, EPI_STORE, false>(a, s);
+    else if (K > 128 && gccnmf_tune_dma && gccnmf_tune_ablate != 128) rc = gccnmf_launch_gemm_dma<false, false, EPI_STORE, false>(a, s);
     else rc = (K > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s)
                         : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
     if (rc) return rc;
@@ -291,6 +293,9 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
     if (gcc_small_launch(batch, a.M, a.N, a.Kd))
         return tail ? gccnmf_launch_gemm_ring<true, false, EPI_PHASE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_PHASE, false>(a, s);
     const bool tall = a.M > 128;
+    // batch scale: the LDS-DMA throughput tile (main loop of K1) with the generic phase epilogue
+    if (tall && gccnmf_tune_dma && gccnmf_tune_ablate != 128)
+        return tail ? gccnmf_launch_gemm_dma<true, false, EPI_PHASE, true>(a, s) : gccnmf_launch_gemm_dma<true, false, EPI_PHASE, false>(a, s);
     if (tall) return tail ? gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, true>(a, s)
                           : gccnmf_launch_gemm<4, 1, true, false, EPI_PHASE, false>(a, s);
     return tail ? gccnmf_launch_gemm<1, 4, true, false, EPI_PHASE, true>(a, s)
