@@ -19,6 +19,12 @@
 #include <type_traits>
 #include "gemm_mfma.h"
 
+// build-time timing experiments (results invalid): GEMM_DMA_ABL bit 1 = no fragment reads in the main loop, bit 2 = no split barrier;
+// GEMM_DMA_SKIP_FROM = n: only the first n LDS-DMA pieces of a k-tile are issued
+#ifndef GEMM_DMA_ABL
+#define GEMM_DMA_ABL 0
+#endif
+
 typedef __attribute__((address_space(3))) void* gemm_lds_ptr;
 typedef __attribute__((address_space(1))) const void* gemm_glb_ptr;
 
@@ -440,6 +446,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
     // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
     auto dma_piece = [&](const int piece, const int kt, const int buf) {
+#ifdef GEMM_DMA_SKIP_FROM
+        if (piece >= GEMM_DMA_SKIP_FROM) return;                    // timing experiment (results invalid): fewer pieces per k-tile
+#endif
         if (piece < 8) {
             gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece], lds0 + 4 * (buf * SBUF + (wave * 8 + piece) * 256));
         } else if (piece == 8) {
@@ -603,7 +612,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         const unsigned ldsC = lds0 + 4 * CUR * SBUF, ldsN = lds0 + 4 * (CUR ^ 1) * SBUF;
         const int ktn = min(kt + 1, nkt - 1);
         GEMM_PROBE(0);
+#if !(GEMM_DMA_ABL & 1)
         read_group1(ldsC);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (wave_active) {
             if (SPREAD == 0) {
@@ -649,12 +660,16 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 GEMM_PROBE_SET(3);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(GEMM_DMA_ABL & 2)
                 gemm_barrier_arrive(arrivals_addr);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (e == GEMM_DMA_WAIT_E - 1) {
                 __builtin_amdgcn_sched_barrier(0);
+#if !(GEMM_DMA_ABL & 2)
                 seen = gemm_barrier_peek(arrivals_addr);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (e == GEMM_DMA_WAIT_E) {
@@ -662,9 +677,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 // target of the next step's pieces)
                 __builtin_amdgcn_sched_barrier(0);
                 GEMM_PROBE_SET(4);
+#if !(GEMM_DMA_ABL & 2)
                 gemm_barrier_wait(arrivals_addr, 4u * (unsigned)(kt + 1), seen);
+#endif
                 GEMM_PROBE_SET(5);
+#if !(GEMM_DMA_ABL & 1)
                 read_group0(ldsN);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (wave_active) {
