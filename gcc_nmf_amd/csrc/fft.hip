@@ -162,6 +162,126 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     y[sig * L + m] = acc * gain;
 }
 
+
+// Inverse STFT AND overlap-add in one pass (the windowed time frames never go to HBM: 15 MB written + read back per file at
+// K = 1024 in the two-kernel form).  A workgroup owns the output samples of G = ISTFT_SUB * ISTFT_TB consecutive hops of one
+// signal pair; it transforms frames t0-H .. t0+G-1 (H = ceil(N/hop)-1 halo frames that also reach into its range: 9 % more
+// spectrogram reads at N/hop = 4) in ascending sub-batches of ISTFT_TB frames and adds each frame into a sliding LDS accumulator
+// in ASCENDING frame order, every sample starting from 0 -- the order librosaSTFT.py:275-281 accumulates in; the result equals that
+// of istft_frames_kernel + istft_ola_kernel to the last bit or two (the accumulation is identical, but the compiler contracts the
+// FFT butterflies of the two kernels into fmas differently: measured max 3.7e-9 at |y| ~ 0.06).  grid = batch * (nsig/2) * ceil(T / G).
+#define ISTFT_TB 4
+#define ISTFT_SUB 8
+__global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int hop, int T,
+                                                             const float* __restrict__ window, const float2* __restrict__ twiddle,
+                                                             int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
+    constexpr int TB = ISTFT_TB, G = ISTFT_TB * ISTFT_SUB;
+    const int zstride = N + FFT_ZPAD;
+    float2* z = fft_smem;
+    float2* tw = fft_smem + TB * zstride;
+    const int span = N + hop * (TB - 1);                  // samples one sub-batch touches
+    float* acc_a = (float*)(tw + N / 2);                  // [span] per signal of the pair
+    float* acc_b = acc_a + span;
+    const int groups = (T + G - 1) / G, npairs = nsig / 2;
+    int id = blockIdx.x;
+    const int g = id % groups;
+    id /= groups;
+    const int pr = id % npairs, b = id / npairs;
+    const int t0 = g * G, t_end = min(t0 + G, T);
+    const int halo = (N + hop - 1) / hop - 1;
+    const int t_first = max(t0 - halo, 0);
+    const long plane = (long)Fp * Tp;
+    const float2* Sa = spec + ((long)b * nsig + 2 * pr) * plane;
+    const float2* Sb = Sa + plane;
+    float* ya = y + ((long)b * nsig + 2 * pr) * L;
+    float* yb = ya + L;
+    // owned samples of the untrimmed stream: [t0 * hop, t_end * hop), the last group to the end of the last frame
+    const long own_lo = (long)t0 * hop, own_hi = (t_end == T) ? (long)(T - 1) * hop + N : (long)t_end * hop;
+    const float invN = 1.0f / (float)N;
+
+    for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
+    for (int i = threadIdx.x; i < 2 * span; i += FFT_NT) acc_a[i] = 0.f;
+    long base = (long)t_first * hop;                      // untrimmed sample index of acc[0]
+    for (int fs = t_first; fs < t_end; fs += TB) {
+        // samples before this sub-batch's first frame are final: hand them out, slide the accumulator
+        const int shift = (int)((long)fs * hop - base);
+        if (shift > 0) {
+            __syncthreads();
+            float keep_a[8], keep_b[8];                   // span / FFT_NT <= 8 for N <= 2048
+            for (int i = threadIdx.x, r = 0; i < span; i += FFT_NT, ++r) {
+                const float va = acc_a[i], vb = acc_b[i];
+                if (i < shift) {
+                    const long sg = base + i;
+                    if (sg >= own_lo && sg < own_hi) {
+                        const long m = sg - trim;
+                        if (m >= 0 && m < L) {
+                            ya[m] = va * gain;
+                            yb[m] = vb * gain;
+                        }
+                    }
+                }
+                keep_a[r] = (i + shift < span) ? acc_a[i + shift] : 0.f;
+                keep_b[r] = (i + shift < span) ? acc_b[i + shift] : 0.f;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x, r = 0; i < span; i += FFT_NT, ++r) {
+                acc_a[i] = keep_a[r];
+                acc_b[i] = keep_b[r];
+            }
+            base += shift;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
+            const int f = idx / TB, tb = idx - f * TB;
+            const int t = fs + tb;
+            float2 fa = make_float2(0.f, 0.f), fb = fa;
+            if (t < t_end) {
+                const float2 sa = Sa[(long)f * Tp + t], sb = Sb[(long)f * Tp + t];
+                fa = make_float2(sa.x, -sa.y);   // istft undoes the stored conjugate (librosaSTFT.py:278)
+                fb = make_float2(sb.x, -sb.y);
+            }
+            if (f == 0 || f == N / 2) {          // ifft(...).real keeps only the real part of these two bins
+                fa.y = 0.f;
+                fb.y = 0.f;
+            }
+            float2* zz = z + tb * zstride;
+            zz[bitrev(f, logN)] = make_float2(fa.x - fb.y, fa.y + fb.x);
+            if (f != 0 && f != N / 2) zz[bitrev(N - f, logN)] = make_float2(fa.x + fb.y, fb.x - fa.y);
+        }
+        __syncthreads();
+        fft_stages<true, TB>(z, tw, N, logN, zstride);
+        // every thread owns the accumulator positions i = tid, tid + NT, ...: frames added in ascending order, no hazards
+        for (int i = threadIdx.x; i < span; i += FFT_NT) {
+            float va = acc_a[i], vb = acc_b[i];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int n = i - tb * hop;
+                if (n >= 0 && n < N && fs + tb < t_end) {
+                    const float2 v = z[tb * zstride + n];
+                    const float w = window[n];
+                    // (explicitly rounded products and sums: the reference adds whole frames, no fma across the window product)
+                    va = __fadd_rn(va, __fmul_rn(w, __fmul_rn(v.x, invN)));
+                    vb = __fadd_rn(vb, __fmul_rn(w, __fmul_rn(v.y, invN)));
+                }
+            }
+            acc_a[i] = va;
+            acc_b[i] = vb;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < span; i += FFT_NT) {
+        const long sg = base + i;
+        if (sg >= own_lo && sg < own_hi) {
+            const long m = sg - trim;
+            if (m >= 0 && m < L) {
+                ya[m] = acc_a[i] * gain;
+                yb[m] = acc_b[i] * gain;
+            }
+        }
+    }
+}
+
 // ---- int16 egress (gccNMF/wavfile.py:39-48, :92-131) ---------------------------------------------------------
 // peak[g] = max |y| over the 2*L samples of group g (= one target of one file: what one wavwrite call sees).
 // Non-negative floats order like their bit patterns, so atomicMax on the uint image is exact and order independent -- and
@@ -235,11 +355,27 @@ int gccnmf_stft_stereo_pcm16(const short* pcm, long frame_stride, int n_samples,
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream) {
     const int logN = ilog2_exact(n_fft);
-    if (!spec || !window || !twiddle || !frames || !y || logN < 6 || logN > 12 || hop < 1 || T < 1 || batch < 1 || nsig < 2 ||
-        (nsig & 1))
+    if (!spec || !window || !twiddle || !y || logN < 6 || logN > 12 || hop < 1 || T < 1 || batch < 1 || nsig < 2 || (nsig & 1))
         return GCCNMF_ERR_ARG;
     const int F = n_fft / 2 + 1;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    if (!frames) {      // fused form: no frame buffer, one pass
+        const int trim = center ? n_fft / 2 : 0;
+        const int L = n_fft + hop * (T - 1) - 2 * trim;
+        if (L < 1) return GCCNMF_ERR_ARG;
+        const int span = n_fft + hop * (ISTFT_TB - 1);
+        if (span > 8 * FFT_NT) return GCCNMF_ERR_UNSUPPORTED;          // hop > n_fft / 3 or so: use the two-kernel form
+        const size_t lds = sizeof(float2) * ((size_t)ISTFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) + sizeof(float) * 2 * span;
+        if (lds > 64 * 1024) {
+            if (hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return GCCNMF_ERR_LAUNCH;
+        }
+        const int groups = gccnmf_ceil_div(T, ISTFT_TB * ISTFT_SUB);
+        hipLaunchKernelGGL(istft_fused_kernel, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float2*)spec,
+                           nsig, n_fft, logN, hop, T, window, (const float2*)twiddle, F, p.Fp, p.Tp, trim, L, gain, y);
+        GCCNMF_CHECK_LAUNCH();
+        return GCCNMF_OK;
+    }
     const size_t lds = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {

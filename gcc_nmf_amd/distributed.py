@@ -352,7 +352,7 @@ class HipTimeShard(object):
     def masks_and_spectrograms(self):
         self.e.masks()
         self.e.reconstruct()
-        self.e.istft()                                           # windowed time frames of the own spectrogram estimates -> e.frames
+        self.e.istft(keep_frames=True)                           # windowed time frames of the own spectrogram estimates -> e.frames
 
     @_on_device
     def tail_frames(self):

@@ -162,7 +162,10 @@ class GCCNMFEngine(object):
             self.argmax = torch.zeros((B, g.Kp, g.Tp), dtype=torch.uint8, device=dev)
             self.ws_rec = z(self.lib.gccnmf_reconstruct_workspace_floats(T, g.K, g.S, B))
             self.spec = z(B, 2 * g.S, g.Fp, g.Tp, 2)
-            self.frames = z(B, 2 * g.S, T, self.n_fft)
+            # windowed time frames [B][2S][T][n_fft]: only the two-kernel iSTFT needs them (allocated on first use); the default is the
+            # fused inverse-transform + overlap-add pass, available while n_fft + 3 * hop <= 2048
+            self.frames = None
+            self.fused_istft = self.n_fft + 3 * self.hop <= 2048
             self.y = z(B, g.S, 2, self.L)
             self.pcm_in = None        # set by upload_pcm16(): the STFT then reads int16 frames directly
             self.pcm_out = None
@@ -236,11 +239,17 @@ class GCCNMFEngine(object):
                    'gccnmf_reconstruct')
 
     @_on_device
-    def istft(self):
+    def istft(self, keep_frames=False):
+        """spec -> y.  keep_frames: the two-kernel form that also leaves the windowed time frames in ``self.frames``."""
         g = self.g
         gain = np.float32(self.hop / float(self.n_fft) * 2)           # gccNMFFunctions.py:155
+        frames = None
+        if keep_frames or not self.fused_istft:
+            if self.frames is None:
+                self.frames = torch.zeros((self.batch, 2 * g.S, g.T, self.n_fft), dtype=torch.float32, device=self.device)
+            frames = self.frames
         _hip.check(self.lib.gccnmf_istft_ola(_ptr(self.spec), 2 * g.S, self.n_fft, self.hop, g.T, self.batch, _ptr(self.window),
-                                             _ptr(self.twiddle), gain, 1, _ptr(self.frames), _ptr(self.y), _stream()),
+                                             _ptr(self.twiddle), gain, 1, _ptr(frames), _ptr(self.y), _stream()),
                    'gccnmf_istft_ola')
 
     @_on_device

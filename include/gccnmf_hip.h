@@ -161,7 +161,8 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
  * getTargetSignalEstimates (gccNMFFunctions.py:153-163 -> librosaSTFT.py:241-286, center=True).
  *   spec   [batch][nsig][Fp][Tp] complex (nsig must be even: signals are inverse-transformed in pairs)
  *   window [n_fft] synthesis window; twiddle as for the forward transform
- *   frames [batch][nsig][T][n_fft] float32 scratch
+ *   frames [batch][nsig][T][n_fft] float32 scratch, or NULL: inverse transform and overlap-add fused in one pass (same accumulation
+ *          order, no frame buffer; needs n_fft + 3*hop <= 2048, else GCCNMF_ERR_UNSUPPORTED)
  *   center != 0 trims n_fft/2 samples at both ends (the reference path), 0 keeps all n_fft + hop*(T-1)
  *   y      [batch][nsig][L] float32 out, L = n_fft + hop*(T-1) - (center ? n_fft : 0) */
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,

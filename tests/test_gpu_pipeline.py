@@ -423,3 +423,20 @@ def test_unmodified_reference_driver_on_hardware(tmp_path):
     # truncation to int16 turns any float difference into <= 1 LSB; a near-tie coefficient flip moves one atom of one frame
     # and can reach a few LSB on a handful of samples (measured on MI355X: worst 2 LSB)
     assert worst <= 4 and beyond <= 1e-4 * total
+
+
+@pytest.mark.parametrize('n,hop,K,batch', [(160000, 256, 64, 3), (52000, 128, 32, 2), (33000, 256, 16, 1), (9000, 256, 16, 1)])
+def test_fused_istft_overlap_add_equals_the_two_kernel_form(n, hop, K, batch):
+    """The one-pass inverse STFT + overlap-add (no frame buffer) against frames kernel + overlap-add kernel, including the first / last
+    hops of the stream and frame counts that are not a multiple of the 32 hops a workgroup owns.  Same accumulation order; the
+    last bit may differ because the two kernels' FFT butterflies are fma-contracted differently (measured max 3.7e-9 at |y| 0.06)."""
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    xs = synthetic_batch(40, batch, numSamples=n)
+    e = engine(n, hopSize=hop, dictionarySize=K, numIterations=3, batch=batch)
+    assert e.fused_istft
+    e.separate(xs)
+    y_fused = e.y.clone()
+    e.y.zero_()
+    e.istft(keep_frames=True)
+    assert (e.y - y_fused).abs().max().item() < 2e-7 * y_fused.abs().max().item()
+    assert torch.isfinite(y_fused).all() and y_fused.abs().max() > 0
