@@ -170,8 +170,12 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 // in ASCENDING frame order, every sample starting from 0 -- the order librosaSTFT.py:275-281 accumulates in; the result equals that
 // of istft_frames_kernel + istft_ola_kernel to the last bit or two (the accumulation is identical, but the compiler contracts the
 // FFT butterflies of the two kernels into fmas differently: measured max 3.7e-9 at |y| ~ 0.06).  grid = batch * (nsig/2) * ceil(T / G).
+#ifndef ISTFT_TB
 #define ISTFT_TB 4
+#endif
+#ifndef ISTFT_SUB
 #define ISTFT_SUB 8
+#endif
 __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int hop, int T,
                                                              const float* __restrict__ window, const float2* __restrict__ twiddle,
                                                              int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y) {
