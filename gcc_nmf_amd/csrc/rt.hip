@@ -75,81 +75,86 @@ __global__ __launch_bounds__(FFT_NT) void rt_frames_kernel(const float* __restri
     }
 }
 
-// ---- rt_gccnmf: grid = (Kp/64, Tc); 4 waves = 2 tau-tile lanes x 2 atom tiles of 32 ------------------------
+// ---- rt_gccnmf: grid = (Kp/32, Tc); 32 atoms per workgroup, the 4 waves split the reduction over f ------------------------------
 // MFMA 32x32x2: A[i = tau][k = f] = G[f][tau] built on the fly from the steering tables, B[k = f][j = atom] = W[f][atom].
+// Latency matters here, not throughput (33.7 MFLOP per frame): the first version ran 16 workgroups with a 129-step chain of
+// dependent global loads (31 us).  Now every wave owns a quarter of the frequency rows (33 steps, the loads of 8 steps issued
+// together), the four partial accumulators meet in LDS, and 32 atoms per workgroup double the number of CUs at work.
 __global__ __launch_bounds__(256) void rt_gccnmf_kernel(const float2* __restrict__ C, const float* __restrict__ cosT,
                                                         const float* __restrict__ sinT, const float* __restrict__ W, int F, int K,
                                                         int Kp, int D, int Dp, int Tc, const float* __restrict__ target,
                                                         int target_mode, float* __restrict__ HMask, int* __restrict__ argmaxTDOA) {
-    __shared__ float s_val[2][64];
-    __shared__ int s_idx[2][64];
-    const int t = blockIdx.y, k0 = blockIdx.x * 64;
+    __shared__ float s_part[3][16][64];                   // partial accumulators of waves 1-3
+    const int t = blockIdx.y, k0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int kt = wave & 1, tlane = wave >> 1;
-    const int atom = k0 + kt * 32 + l31;
+    const int atom = k0 + l31;
+    // frequency rows of this wave: an even number per wave so that the two lane halves (k = 0 / 1 of an MFMA step) pair up
+    const int per = ((F + 7) / 8) * 2;
+    const int f_lo = wave * per, f_hi = min(f_lo + per, F);
+    const int steps = (f_hi - f_lo + 1) / 2;
     float best_val = -INFINITY;
     int best_idx = 0;
-    const int steps = (F + 1) / 2;
-    for (int tt = tlane; tt * 32 < Dp; tt += 2) {
+    for (int tt = 0; tt * 32 < Dp; ++tt) {
         rt_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const int tau = tt * 32 + l31;
-        for (int p = 0; p < steps; ++p) {
-            const int f = 2 * p + hh;
-            float a = 0.f, b = 0.f;
-            if (f < F) {
-                const float2 c = C[(long)f * Tc + t];
-                a = c.x * cosT[(long)f * Dp + tau] + c.y * sinT[(long)f * Dp + tau];
-                b = W[(long)f * Kp + atom];
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        // arg-max over this tile's 32 TDOAs for the lane's atom: rows (r&3) + 8*(r>>2) + 4*hh, ascending within a lane
+        for (int p0 = 0; p0 < steps; p0 += 8) {
+            float av[8], bv[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float v = acc[r];
-            if (row < D && (v > best_val || (v == best_val && row < best_idx))) {
-                best_val = v;
-                best_idx = row;
+            for (int u = 0; u < 8; ++u) {                  // 8 steps' loads in flight together (clamped row, masked below)
+                const int f = min(f_lo + 2 * (p0 + u) + hh, F - 1);
+                const float2 c = C[(long)f * Tc + t];
+                av[u] = c.x * cosT[(long)f * Dp + tau] + c.y * sinT[(long)f * Dp + tau];
+                bv[u] = W[(long)f * Kp + atom];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = (p0 + u) < steps && (f_lo + 2 * (p0 + u) + hh) < f_hi;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u] : 0.f, ok ? bv[u] : 0.f, acc, 0, 0, 0);
             }
         }
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_part[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // total = ((w0 + w1) + w2) + w3, then the arg-max over this tile's 32 TDOAs for the lane's atom:
+            // rows (r&3) + 8*(r>>2) + 4*hh, ascending within a lane
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ((acc[r] + s_part[0][r][lane]) + s_part[1][r][lane]) + s_part[2][r][lane];
+                const int row = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < D && (v > best_val || (v == best_val && row < best_idx))) {
+                    best_val = v;
+                    best_idx = row;
+                }
+            }
+        }
+        __syncthreads();
     }
-    // other row half of the same wave, then the other tau-lane wave of the same atom tile
-    {
-        const float ov = __shfl_xor(best_val, 32);
+    if (wave == 0) {
+        const float ov = __shfl_xor(best_val, 32);        // the other row half
         const int oi = __shfl_xor(best_idx, 32);
         if (ov > best_val || (ov == best_val && oi < best_idx)) {
             best_val = ov;
             best_idx = oi;
         }
-    }
-    if (hh == 0) {
-        s_val[tlane][kt * 32 + l31] = best_val;
-        s_idx[tlane][kt * 32 + l31] = best_idx;
-    }
-    __syncthreads();
-    if (tid < 64 && (k0 + tid) < K) {
-        float v = s_val[0][tid];
-        int i = s_idx[0][tid];
-        const float v1 = s_val[1][tid];
-        const int i1 = s_idx[1][tid];
-        if (v1 > v || (v1 == v && i1 < i)) {
-            v = v1;
-            i = i1;
+        if (hh == 0 && atom < K) {
+            int i = best_idx;
+            if (!(best_val > -INFINITY)) i = 0;           // every score NaN (or D == 0): numpy.argmax of an all-NaN column is 0
+            const float tgt = target[0], eps = target[1], beta = target[2], nf = target[3];
+            const float dist = fabsf((float)i - tgt);
+            float m;
+            if (target_mode == 0)
+                m = dist < eps ? 1.f : 0.f;                                   // TARGET_MODE_BOXCAR (:263)
+            else
+                m = expf(-powf(dist / eps, beta)) / (1.f + nf) + nf;          // TARGET_MODE_WINDOW_FUNCTION (:265)
+            HMask[(long)atom * Tc + t] = m;
+            if (argmaxTDOA) argmaxTDOA[(long)atom * Tc + t] = i;
         }
-        if (!(v > -INFINITY)) i = 0;          // every score NaN (or D == 0): numpy.argmax of an all-NaN column is 0
-        const float tgt = target[0], eps = target[1], beta = target[2], nf = target[3];
-        const float dist = fabsf((float)i - tgt);
-        float m;
-        if (target_mode == 0)
-            m = dist < eps ? 1.f : 0.f;                                   // TARGET_MODE_BOXCAR (:263)
-        else
-            m = expf(-powf(dist / eps, beta)) / (1.f + nf) + nf;          // TARGET_MODE_WINDOW_FUNCTION (:265)
-        HMask[(long)(k0 + tid) * Tc + t] = m;
-        if (argmaxTDOA) argmaxTDOA[(long)(k0 + tid) * Tc + t] = i;
     }
 }
 
@@ -312,8 +317,9 @@ __global__ __launch_bounds__(256) void rt_fill_kernel(float* __restrict__ p, flo
 }
 
 // r[f][col] = |X_c[f][t]| / sum_k W[f][k] h[k][col]; one wave per frequency row, grid = ceil(F/4)
+// first != 0: h is still all ones (no fill pass: the first update reads no coefficients and WRITES them)
 __global__ __launch_bounds__(256) void rt_wh_kernel(const float* __restrict__ W, const float* __restrict__ Hc, const float2* __restrict__ X,
-                                                    float* __restrict__ Rv, int F, int K, int Kp, int Tc) {
+                                                    float* __restrict__ Rv, int F, int K, int Kp, int Tc, int first) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f = blockIdx.x * 4 + wave;
     if (f >= F) return;
@@ -321,7 +327,11 @@ __global__ __launch_bounds__(256) void rt_wh_kernel(const float* __restrict__ W,
     const float* Wr = W + (long)f * Kp;
     for (int col = 0; col < ncol; ++col) {
         float s = 0.f;
-        for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], Hc[(long)k * ncol + col], s);
+        if (first) {
+            for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], 1.f, s);
+        } else {
+            for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], Hc[(long)k * ncol + col], s);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) {
@@ -332,22 +342,27 @@ __global__ __launch_bounds__(256) void rt_wh_kernel(const float* __restrict__ W,
     }
 }
 
-// h[k][col] *= (sum_f W[f][k] r[f][col]) / colsumW[k]; 64 atoms x 4 frequency phases per workgroup, grid = Kp/64
+// h[k][col] *= (sum_f W[f][k] r[f][col]) / colsumW[k]; 16 atoms x 16 frequency phases per workgroup, grid = Kp/16 (the first version
+// had 64 x 4: 16 workgroups with a 65-step chain of dependent loads, 17 us; now 64 workgroups, 17 independent loads per thread)
 __global__ __launch_bounds__(256) void rt_hupdate_kernel(const float* __restrict__ W, const float* __restrict__ Rv,
                                                          const float* __restrict__ colsumW, float* __restrict__ Hc, int F, int K, int Kp,
-                                                         int Tc) {
-    __shared__ float red[256];
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + c;
+                                                         int Tc, int first) {
+    __shared__ float red[4][16];
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 16 + c;
     const int ncol = 2 * Tc;
     for (int col = 0; col < ncol; ++col) {
         float s = 0.f;
-        for (int f = q; f < F; f += 4) s = fmaf(W[(long)f * Kp + k], Rv[(long)f * ncol + col], s);
-        red[threadIdx.x] = s;
+#pragma unroll 4
+        for (int f = q; f < F; f += 16) s = fmaf(W[(long)f * Kp + k], Rv[(long)f * ncol + col], s);
+        s += __shfl_xor(s, 16);                            // the 4 frequency phases of this wave
+        s += __shfl_xor(s, 32);
+        if ((threadIdx.x & 63) < 16) red[wave][c] = s;
         __syncthreads();
-        if (q == 0 && k < K) {
-            const float num = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
-            Hc[(long)k * ncol + col] *= num / colsumW[k];
+        if (threadIdx.x < 16 && k < K) {
+            const float num = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            const float h = first ? 1.f : Hc[(long)k * ncol + col];
+            Hc[(long)k * ncol + col] = h * (num / colsumW[k]);
         }
         __syncthreads();
     }
@@ -396,7 +411,11 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                                const float* synthesis_window, const float* twiddle, const float* colsumW, float* Hcoef, float* Rv,
                                int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp, int numTDOAHistory,
                                int target_mode, int separation_enabled, int localization_enabled, int localization_window,
-                               int frames_mode, int numHUpdates, int out_delay_blocks, void* stream) {
+                               int frames_mode_bits, int numHUpdates, int out_delay_blocks, void* stream) {
+    // frames_mode_bits: 1 = frames mode (above); 2 = leave the localisation kernel out of this call; 4 = ONLY the localisation kernel
+    // (2 then 4 = the same work in two calls, so that a host can fetch block_out before the tracking update has run)
+    const int frames_mode = frames_mode_bits & 1;
+    const bool skip_localize = frames_mode_bits & 2, only_localize = frames_mode_bits & 4;
     const int logN = ilog2_exact(windowSize);
     if (!in_ring || !out_ring || !X || !Y || !C || !HMask || !tfMask || !hist || !hist_pos || !target || !W || !cosT || !sinT ||
         !window || !synthesis_window || !twiddle || (!frames_mode && (!block_in || !block_out)))
@@ -412,6 +431,14 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
     const int start_step = frames_mode ? windowSize : hopSize;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float2) * (windowSize + windowSize / 2);
+    int Dq = 64;
+    while (Dq < D) Dq *= 2;                 // power of two so that 1024 % Dq == 0
+    if (only_localize) {
+        hipLaunchKernelGGL(rt_localize_kernel, dim3(1), dim3(1024), 0, s, (const float2*)C, cosT, sinT, F, D, Dp, Dq, Tc, hist,
+                           numTDOAHistory, hist_pos, localization_enabled, localization_window, target, gccphat);
+        GCCNMF_CHECK_LAUNCH();
+        return GCCNMF_OK;
+    }
     if (!frames_mode) {
         hipLaunchKernelGGL(rt_shift_kernel, dim3(1), dim3(1024), 0, s, in_ring, out_ring, block_in, blockSize, ring);
         GCCNMF_CHECK_LAUNCH();
@@ -420,7 +447,7 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                        window, (const float2*)twiddle, (float2*)X, (float2*)C);
     GCCNMF_CHECK_LAUNCH();
     if (separation_enabled) {
-        hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 64, Tc), dim3(256), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
+        hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 32, Tc), dim3(256), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
                            target, target_mode, HMask, argmaxTDOA);
         GCCNMF_CHECK_LAUNCH();
         if (numHUpdates == 0) {
@@ -428,12 +455,11 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                                (float2*)Y, tfMask);
             GCCNMF_CHECK_LAUNCH();
         } else {
-            hipLaunchKernelGGL(rt_fill_kernel, dim3(gccnmf_ceil_div(Kp * 2 * Tc, 256)), dim3(256), 0, s, Hcoef, 1.f, Kp * 2 * Tc);
-            GCCNMF_CHECK_LAUNCH();
-            for (int it = 0; it < numHUpdates; ++it) {
-                hipLaunchKernelGGL(rt_wh_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, Hcoef, (const float2*)X, Rv, F, K, Kp, Tc);
+            for (int it = 0; it < numHUpdates; ++it) {      // h0 = 1 is implicit in the first update (no fill pass)
+                hipLaunchKernelGGL(rt_wh_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, Hcoef, (const float2*)X, Rv, F, K, Kp, Tc,
+                                   it == 0 ? 1 : 0);
                 GCCNMF_CHECK_LAUNCH();
-                hipLaunchKernelGGL(rt_hupdate_kernel, dim3(Kp / 64), dim3(256), 0, s, W, Rv, colsumW, Hcoef, F, K, Kp, Tc);
+                hipLaunchKernelGGL(rt_hupdate_kernel, dim3(Kp / 16), dim3(256), 0, s, W, Rv, colsumW, Hcoef, F, K, Kp, Tc, it == 0 ? 1 : 0);
                 GCCNMF_CHECK_LAUNCH();
             }
             hipLaunchKernelGGL(rt_tfmask_h_kernel, dim3(gccnmf_ceil_div(F, 4)), dim3(256), 0, s, W, HMask, Hcoef, F, K, Kp, Tc,
@@ -445,8 +471,7 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                        start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, out_delay_blocks, synthesis_window, (const float2*)twiddle,
                        out_ring, block_out);
     GCCNMF_CHECK_LAUNCH();
-    int Dq = 64;
-    while (Dq < D) Dq *= 2;                 // power of two so that 1024 % Dq == 0
+    if (skip_localize) return GCCNMF_OK;
     hipLaunchKernelGGL(rt_localize_kernel, dim3(1), dim3(1024), 0, s, (const float2*)C, cosT, sinT, F, D, Dp, Dq, Tc, hist,
                        numTDOAHistory, hist_pos, localization_enabled, localization_window, target, gccphat);
     GCCNMF_CHECK_LAUNCH();

@@ -177,9 +177,21 @@ class StreamingGCCNMF(object):
         self.p._call(block_in, block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 0, self.outputDelayBlocks)
 
     def process_block(self, block):
-        self.block_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))
-        self.process_block_device(self.block_in, self.block_out)
-        return self.block_out.cpu().numpy()
+        """Host block in -> host block out.  The finished block is fetched (pinned buffer, its own event) BEFORE the tracking update
+        of the next block's target has run: that kernel only writes state the next call reads, so it stays off the latency path."""
+        if getattr(self, '_pin_in', None) is None:
+            self._pin_in = torch.zeros((2, self.blockSize), dtype=torch.float32).pin_memory()
+            self._pin_out = torch.zeros((2, self.blockSize), dtype=torch.float32).pin_memory()
+            self._ev_out = torch.cuda.Event()
+        with torch.cuda.device(self.p.device):
+            self._pin_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))
+            self.block_in.copy_(self._pin_in, non_blocking=True)
+            self.p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 2, self.outputDelayBlocks)
+            self._pin_out.copy_(self.block_out, non_blocking=True)
+            self._ev_out.record()
+            self.p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 4, self.outputDelayBlocks)
+            self._ev_out.synchronize()
+        return self._pin_out.numpy().copy()
 
     def process_stream(self, stereoSamples):
         """(2, n) -> (2, n_blocks*blockSize); the whole signal is uploaded once, every block is one device call."""

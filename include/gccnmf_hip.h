@@ -208,6 +208,8 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
  *                                  (gccNMFFunctions.py:76), h0 = 1, per channel; the mask becomes W.(h*HMask) / W.h per channel,
  *                                  tfMask is then [2][F][Tc].  colsumW [Kp] = sum_f W, Hcoef [Kp][2*Tc], Rv [F][2*Tc] scratch.
  *                                  numHUpdates = 0 is exactly gccnmf_rt_process_block (h = 1).
+ *   frames_mode bits               1 = frames mode; 2 = everything but the localisation kernel; 4 = only the localisation kernel
+ *                                  (2 then 4 on the same stream = one call; lets a host fetch block_out before the tracking update)
  *   out_delay_blocks               which finished block is handed out: 2 = the reference (utils.py:116); 1 is complete when
  *                                  the synthesis window spans at most two hops */
 int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* in_ring, float* out_ring, float* X, float* Y, float* C,
