@@ -78,58 +78,83 @@ __global__ __launch_bounds__(FFT_NT) void rt_frames_kernel(const float* __restri
 // ---- rt_gccnmf: grid = (Kp/32, Tc); 32 atoms per workgroup, the 4 waves split the reduction over f ------------------------------
 // MFMA 32x32x2: A[i = tau][k = f] = G[f][tau] built on the fly from the steering tables, B[k = f][j = atom] = W[f][atom].
 // Latency matters here, not throughput (33.7 MFLOP per frame): the first version ran 16 workgroups with a 129-step chain of
-// dependent global loads (31 us).  Now every wave owns a quarter of the frequency rows (33 steps, the loads of 8 steps issued
-// together), the four partial accumulators meet in LDS, and 32 atoms per workgroup double the number of CUs at work.
-__global__ __launch_bounds__(256) void rt_gccnmf_kernel(const float2* __restrict__ C, const float* __restrict__ cosT,
+// dependent global loads (31 us).  Now each of 8 waves owns an eighth of the frequency rows (17 steps at n_fft = 512: ONE batch of
+// loads, all issued before the first use, two TDOA tiles per pass sharing the W and C loads), the partial accumulators meet in
+// LDS, and 32 atoms per workgroup double the number of CUs at work.
+#define RT_G_WAVES 8
+#define RT_G_CHUNK 17
+__global__ __launch_bounds__(64 * RT_G_WAVES) void rt_gccnmf_kernel(const float2* __restrict__ C, const float* __restrict__ cosT,
                                                         const float* __restrict__ sinT, const float* __restrict__ W, int F, int K,
                                                         int Kp, int D, int Dp, int Tc, const float* __restrict__ target,
                                                         int target_mode, float* __restrict__ HMask, int* __restrict__ argmaxTDOA) {
-    __shared__ float s_part[3][16][64];                   // partial accumulators of waves 1-3
+    __shared__ float s_part[RT_G_WAVES - 1][32][64];      // partial accumulators (two TDOA tiles) of the other waves
     const int t = blockIdx.y, k0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int atom = k0 + l31;
     // frequency rows of this wave: an even number per wave so that the two lane halves (k = 0 / 1 of an MFMA step) pair up
-    const int per = ((F + 7) / 8) * 2;
+    const int per = ((F + 2 * RT_G_WAVES - 1) / (2 * RT_G_WAVES)) * 2;
     const int f_lo = wave * per, f_hi = min(f_lo + per, F);
     const int steps = (f_hi - f_lo + 1) / 2;
     float best_val = -INFINITY;
     int best_idx = 0;
-    for (int tt = 0; tt * 32 < Dp; ++tt) {
-        rt_f32x16 acc;
+    // two TDOA tiles per pass (they share the W and C loads; D = 64 is one pass), 16 steps' loads in flight together
+    for (int tt = 0; tt * 32 < Dp; tt += 2) {
+        rt_f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int tau = tt * 32 + l31;
-        for (int p0 = 0; p0 < steps; p0 += 8) {
-            float av[8], bv[8];
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        const bool two = (tt + 1) * 32 < Dp;
+        const int tau0 = tt * 32 + l31, tau1 = two ? tau0 + 32 : tau0;
+        for (int p0 = 0; p0 < steps; p0 += RT_G_CHUNK) {
+            // raw loads first, ALL of them (the scheduler otherwise sinks them next to their uses and the chunk degenerates into a
+            // chain of one or two outstanding loads: measured 19 us for the kernel), then the arithmetic
+            float2 cv[RT_G_CHUNK];
+            float c0[RT_G_CHUNK], s0[RT_G_CHUNK], c1[RT_G_CHUNK], s1[RT_G_CHUNK], bv[RT_G_CHUNK];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                  // 8 steps' loads in flight together (clamped row, masked below)
+            for (int u = 0; u < RT_G_CHUNK; ++u) {         // (clamped row, masked below)
                 const int f = min(f_lo + 2 * (p0 + u) + hh, F - 1);
-                const float2 c = C[(long)f * Tc + t];
-                av[u] = c.x * cosT[(long)f * Dp + tau] + c.y * sinT[(long)f * Dp + tau];
-                bv[u] = W[(long)f * Kp + atom];
+                cv[u] = C[f * Tc + t];
+                c0[u] = cosT[f * Dp + tau0];
+                s0[u] = sinT[f * Dp + tau0];
+                c1[u] = cosT[f * Dp + tau1];
+                s1[u] = sinT[f * Dp + tau1];
+                bv[u] = W[f * Kp + atom];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RT_G_CHUNK; ++u) {
                 const bool ok = (p0 + u) < steps && (f_lo + 2 * (p0 + u) + hh) < f_hi;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u] : 0.f, ok ? bv[u] : 0.f, acc, 0, 0, 0);
+                const float b = ok ? bv[u] : 0.f;
+                const float a0 = cv[u].x * c0[u] + cv[u].y * s0[u], a1 = cv[u].x * c1[u] + cv[u].y * s1[u];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? a0 : 0.f, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? a1 : 0.f, b, acc1, 0, 0, 0);
             }
         }
         if (wave > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_part[wave - 1][r][lane] = acc[r];
+            for (int r = 0; r < 16; ++r) {
+                s_part[wave - 1][r][lane] = acc0[r];
+                s_part[wave - 1][16 + r][lane] = acc1[r];
+            }
         }
         __syncthreads();
         if (wave == 0) {
-            // total = ((w0 + w1) + w2) + w3, then the arg-max over this tile's 32 TDOAs for the lane's atom:
-            // rows (r&3) + 8*(r>>2) + 4*hh, ascending within a lane
+            // total of the waves' partial sums, then the arg-max over the 32 TDOAs of each tile for the lane's atom:
+            // rows (r&3) + 8*(r>>2) + 4*hh, ascending within a lane, tiles in ascending order
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = ((acc[r] + s_part[0][r][lane]) + s_part[1][r][lane]) + s_part[2][r][lane];
-                const int row = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row < D && (v > best_val || (v == best_val && row < best_idx))) {
-                    best_val = v;
-                    best_idx = row;
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1 && !two) break;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float own = half ? acc1[r] : acc0[r];
+                    float v = own;                              // fixed order: w0 + w1 + ... + w7
+#pragma unroll
+                    for (int w = 0; w < RT_G_WAVES - 1; ++w) v += s_part[w][16 * half + r][lane];
+                    const int row = (tt + half) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (row < D && (v > best_val || (v == best_val && row < best_idx))) {
+                        best_val = v;
+                        best_idx = row;
+                    }
                 }
             }
         }
@@ -287,20 +312,30 @@ __global__ __launch_bounds__(1024) void rt_localize_kernel(const float2* __restr
             s_sum[tau] = m;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            // numpy.argmax: NaN counts as the maximum, first occurrence wins
-            int best = 0;
-            bool best_nan = s_sum[0] != s_sum[0];
-            for (int i = 1; i < D && !best_nan; ++i) {
-                const float v = s_sum[i];
-                if (v != v) {
-                    best = i;
-                    best_nan = true;
-                } else if (v > s_sum[best]) {
-                    best = i;
+        // numpy.argmax: NaN counts as the maximum, first occurrence wins.  Tree reduction over (rank, index) pairs: a NaN ranks
+        // above every number, equal ranks keep the smaller index (the serial scan this replaces cost ~6 us of the call).
+        {
+            const int i = threadIdx.x;
+            float v = (i < D) ? s_sum[i] : -INFINITY;
+            int idx = (i < D) ? i : 0x7fffffff;
+            __syncthreads();
+            for (int w = 512; w > 0; w >>= 1) {
+                s_sum[i] = v;
+                s_cnt[i] = idx;
+                __syncthreads();
+                if (i < w) {
+                    const float ov = s_sum[i + w];
+                    const int oi = s_cnt[i + w];
+                    const bool vn = v != v, on = ov != ov;
+                    const bool take = (on && !vn) || (on == vn && (on ? oi < idx : (ov > v || (ov == v && oi < idx))));
+                    if (take) {
+                        v = ov;
+                        idx = oi;
+                    }
                 }
+                __syncthreads();
             }
-            target[0] = (float)best;
+            if (i == 0) target[0] = (float)idx;
         }
     }
     if (threadIdx.x == 0) hist_pos[0] = pos;
@@ -325,19 +360,28 @@ __global__ __launch_bounds__(256) void rt_wh_kernel(const float* __restrict__ W,
     if (f >= F) return;
     const int ncol = 2 * Tc;
     const float* Wr = W + (long)f * Kp;
-    for (int col = 0; col < ncol; ++col) {
-        float s = 0.f;
+    for (int t = 0; t < Tc; ++t) {                         // both channels of a frame in one pass over the row of W
+        float s0 = 0.f, s1 = 0.f;
         if (first) {
-            for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], 1.f, s);
+            for (int k = lane; k < K; k += 64) s0 = fmaf(Wr[k], 1.f, s0);
+            s1 = s0;
         } else {
-            for (int k = lane; k < K; k += 64) s = fmaf(Wr[k], Hc[(long)k * ncol + col], s);
+#pragma unroll 4
+            for (int k = lane; k < K; k += 64) {
+                const float w = Wr[k];
+                const float2 h = *(const float2*)(Hc + (long)k * ncol + 2 * t);
+                s0 = fmaf(w, h.x, s0);
+                s1 = fmaf(w, h.y, s1);
+            }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o);
+            s1 += __shfl_xor(s1, o);
+        }
         if (lane == 0) {
-            const int t = col >> 1, c = col & 1;
-            const float2 x = X[((long)c * F + f) * Tc + t];
-            Rv[(long)f * ncol + col] = hypotf(x.x, x.y) / s;
+            const float2 xl = X[(long)f * Tc + t], xr = X[((long)F + f) * Tc + t];
+            *(float2*)(Rv + (long)f * ncol + 2 * t) = make_float2(hypotf(xl.x, xl.y) / s0, hypotf(xr.x, xr.y) / s1);
         }
     }
 }
@@ -377,24 +421,32 @@ __global__ __launch_bounds__(256) void rt_tfmask_h_kernel(const float* __restric
     if (f >= F) return;
     const int ncol = 2 * Tc;
     const float* Wr = W + (long)f * Kp;
-    for (int col = 0; col < ncol; ++col) {
-        const int t = col >> 1, c = col & 1;
-        float num = 0.f, den = 0.f;
+    for (int t = 0; t < Tc; ++t) {                         // both channels of a frame in one pass over the row of W
+        float n0 = 0.f, d0 = 0.f, n1 = 0.f, d1 = 0.f;
+#pragma unroll 4
         for (int k = lane; k < K; k += 64) {
-            const float wh = Wr[k] * Hc[(long)k * ncol + col];
-            den += wh;
-            num = fmaf(wh, HMask[(long)k * Tc + t], num);
+            const float w = Wr[k], hm = HMask[(long)k * Tc + t];
+            const float2 h = *(const float2*)(Hc + (long)k * ncol + 2 * t);
+            const float wh0 = w * h.x, wh1 = w * h.y;
+            d0 += wh0;
+            d1 += wh1;
+            n0 = fmaf(wh0, hm, n0);
+            n1 = fmaf(wh1, hm, n1);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            num += __shfl_xor(num, o);
-            den += __shfl_xor(den, o);
+            n0 += __shfl_xor(n0, o);
+            d0 += __shfl_xor(d0, o);
+            n1 += __shfl_xor(n1, o);
+            d1 += __shfl_xor(d1, o);
         }
         if (lane == 0) {
-            const float m = num / den;
-            tfMask[((long)c * F + f) * Tc + t] = m;
-            const float2 a = X[((long)c * F + f) * Tc + t];
-            Y[((long)c * F + f) * Tc + t] = make_float2(m * a.x, m * a.y);
+            const float m0 = n0 / d0, m1 = n1 / d1;
+            tfMask[(long)f * Tc + t] = m0;
+            tfMask[((long)F + f) * Tc + t] = m1;
+            const float2 a = X[(long)f * Tc + t], b = X[((long)F + f) * Tc + t];
+            Y[(long)f * Tc + t] = make_float2(m0 * a.x, m0 * a.y);
+            Y[((long)F + f) * Tc + t] = make_float2(m1 * b.x, m1 * b.y);
         }
     }
 }
@@ -447,7 +499,7 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                        window, (const float2*)twiddle, (float2*)X, (float2*)C);
     GCCNMF_CHECK_LAUNCH();
     if (separation_enabled) {
-        hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 32, Tc), dim3(256), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
+        hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 32, Tc), dim3(64 * RT_G_WAVES), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
                            target, target_mode, HMask, argmaxTDOA);
         GCCNMF_CHECK_LAUNCH();
         if (numHUpdates == 0) {
