@@ -16,7 +16,7 @@
 // grid = batch * ceil(T / TB); dynamic LDS = (TB*(N+ZPAD) + N/2) float2.
 // PCM16 = true: x points at interleaved int16 frames [n][2] (a wav file's data chunk); the int16 -> float32 / 32768
 // conversion of wavfile.pcm2float (gccNMF/wavfile.py:57-89) and the de-interleave ride on the load (4 bytes per lane, coalesced).
-template <bool PCM16>
+template <bool PCM16, int TB>
 __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __restrict__ x, long x_stride, int n_samples, int N,
                                                              int logN, int hop, int T, const float* __restrict__ window,
                                                              const float2* __restrict__ twiddle, float2* __restrict__ X,
@@ -25,15 +25,15 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
     const int zstride = N + FFT_ZPAD;
     float2* z = fft_smem;
-    float2* tw = fft_smem + FFT_TB * zstride;
-    const int groups = (T + FFT_TB - 1) / FFT_TB;
-    const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * FFT_TB;
+    float2* tw = fft_smem + TB * zstride;
+    const int groups = (T + TB - 1) / TB;
+    const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * TB;
     const float* xl = x + b * x_stride;
     const float* xr = xl + n_samples;
     const short2* pcm = (const short2*)x + b * x_stride;      // PCM16: x_stride counts stereo frames
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
-    for (int idx = threadIdx.x; idx < FFT_TB * N; idx += FFT_NT) {
+    for (int idx = threadIdx.x; idx < TB * N; idx += FFT_NT) {
         const int tb = idx / N, n = idx - tb * N;
         const int t = t0 + tb;
         float2 v = make_float2(0.f, 0.f);
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
         z[tb * zstride + bitrev(n, logN)] = v;
     }
     __syncthreads();
-    fft_stages<false>(z, tw, N, logN, zstride);
+    fft_stages<false, TB>(z, tw, N, logN, zstride);
 
     const long plane = (long)Fp * Tp;
     float2* Xb = X + (long)b * 2 * plane;
-    for (int idx = threadIdx.x; idx < F * FFT_TB; idx += FFT_NT) {
-        const int f = idx / FFT_TB, tb = idx - f * FFT_TB;
+    for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
+        const int f = idx / TB, tb = idx - f * TB;
         const int t = t0 + tb;
         if (t >= T) continue;
         const float2 zk = z[tb * zstride + f];
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
 }
 
 // grid = batch * (nsig/2) * ceil(T / TB).  Writes windowed time frames [batch][nsig][T][N].
+template <int TB>
 __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int T,
                                                               const float* __restrict__ window,
                                                               const float2* __restrict__ twiddle, float* __restrict__ frames,
@@ -96,21 +97,21 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
     const int zstride = N + FFT_ZPAD;
     float2* z = fft_smem;
-    float2* tw = fft_smem + FFT_TB * zstride;
-    const int groups = (T + FFT_TB - 1) / FFT_TB;
+    float2* tw = fft_smem + TB * zstride;
+    const int groups = (T + TB - 1) / TB;
     const int npairs = nsig / 2;
     int id = blockIdx.x;
     const int g = id % groups;
     id /= groups;
     const int pr = id % npairs, b = id / npairs;
-    const int t0 = g * FFT_TB;
+    const int t0 = g * TB;
     const long plane = (long)Fp * Tp;
     const float2* Sa = spec + ((long)b * nsig + 2 * pr) * plane;
     const float2* Sb = Sa + plane;
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
-    for (int idx = threadIdx.x; idx < F * FFT_TB; idx += FFT_NT) {
-        const int f = idx / FFT_TB, tb = idx - f * FFT_TB;
+    for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
+        const int f = idx / TB, tb = idx - f * TB;
         const int t = t0 + tb;
         float2 fa = make_float2(0.f, 0.f), fb = fa;
         if (t < T) {
@@ -127,12 +128,12 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
         if (f != 0 && f != N / 2) zz[bitrev(N - f, logN)] = make_float2(fa.x + fb.y, fb.x - fa.y);
     }
     __syncthreads();
-    fft_stages<true>(z, tw, N, logN, zstride);
+    fft_stages<true, TB>(z, tw, N, logN, zstride);
 
     const float invN = 1.0f / (float)N;
     float* Fa = frames + (((long)b * nsig + 2 * pr) * T) * N;
     float* Fb = Fa + (long)T * N;
-    for (int idx = threadIdx.x; idx < FFT_TB * N; idx += FFT_NT) {
+    for (int idx = threadIdx.x; idx < TB * N; idx += FFT_NT) {
         const int tb = idx / N, n = idx - tb * N;
         const int t = t0 + tb;
         if (t >= T) continue;
@@ -329,19 +330,28 @@ static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, i
     if ((long)(T - 1) * hop + n_fft > n_samples) return GCCNMF_ERR_ARG;
     const int F = n_fft / 2 + 1;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
-    const size_t lds = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2);
+    // eight frames per workgroup; four when eight no longer fit the 160 KB of LDS (n_fft = 4096)
+    const bool small_tb = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) > 160 * 1024;
+    const int tb = small_tb ? FFT_TB / 2 : FFT_TB;
+    const size_t lds = sizeof(float2) * ((size_t)tb * (n_fft + FFT_ZPAD) + n_fft / 2);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
-    const void* fn = pcm16 ? (const void*)stft_stereo_kernel<true> : (const void*)stft_stereo_kernel<false>;
+    const void* fn = pcm16 ? (small_tb ? (const void*)stft_stereo_kernel<true, FFT_TB / 2> : (const void*)stft_stereo_kernel<true, FFT_TB>)
+                           : (small_tb ? (const void*)stft_stereo_kernel<false, FFT_TB / 2> : (const void*)stft_stereo_kernel<false, FFT_TB>);
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     }
-    const int groups = gccnmf_ceil_div(T, FFT_TB);
-    if (pcm16)
-        hipLaunchKernelGGL(stft_stereo_kernel<true>, dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x,
-                           x_stride, n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp);
-    else
-        hipLaunchKernelGGL(stft_stereo_kernel<false>, dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x,
-                           x_stride, n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp);
+    const int groups = gccnmf_ceil_div(T, tb);
+#define GCCNMF_LAUNCH_STFT(P_, TB_)                                                                                                       \
+    hipLaunchKernelGGL((stft_stereo_kernel<P_, TB_>), dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x, x_stride, \
+                       n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp)
+    if (pcm16) {
+        if (small_tb) GCCNMF_LAUNCH_STFT(true, FFT_TB / 2);
+        else GCCNMF_LAUNCH_STFT(true, FFT_TB);
+    } else {
+        if (small_tb) GCCNMF_LAUNCH_STFT(false, FFT_TB / 2);
+        else GCCNMF_LAUNCH_STFT(false, FFT_TB);
+    }
+#undef GCCNMF_LAUNCH_STFT
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
@@ -380,16 +390,22 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
         GCCNMF_CHECK_LAUNCH();
         return GCCNMF_OK;
     }
-    const size_t lds = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2);
+    const bool small_tb = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) > 160 * 1024;
+    const int tb = small_tb ? FFT_TB / 2 : FFT_TB;
+    const size_t lds = sizeof(float2) * ((size_t)tb * (n_fft + FFT_ZPAD) + n_fft / 2);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)istft_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GCCNMF_ERR_LAUNCH;
+        const void* fn = small_tb ? (const void*)istft_frames_kernel<FFT_TB / 2> : (const void*)istft_frames_kernel<FFT_TB>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     }
-    const int groups = gccnmf_ceil_div(T, FFT_TB);
+    const int groups = gccnmf_ceil_div(T, tb);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, s, (const float2*)spec, nsig,
-                       n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp);
+    if (small_tb)
+        hipLaunchKernelGGL(istft_frames_kernel<FFT_TB / 2>, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, s, (const float2*)spec, nsig,
+                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp);
+    else
+        hipLaunchKernelGGL(istft_frames_kernel<FFT_TB>, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, s, (const float2*)spec, nsig,
+                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp);
     GCCNMF_CHECK_LAUNCH();
     const int trim = center ? n_fft / 2 : 0;
     const int L = n_fft + hop * (T - 1) - 2 * trim;

@@ -62,12 +62,12 @@ def _window_vector(window, win_length, n_fft, inverse=False):
     return pad_center(w, n_fft)
 
 
-SUPPORTED_N_FFT = (64, 128, 256, 512, 1024, 2048)
+SUPPORTED_N_FFT = (64, 128, 256, 512, 1024, 2048, 4096)
 
 
 def _check_n_fft(n_fft):
-    """The device FFT is a radix-2 kernel that keeps eight frames of one workgroup in LDS: powers of two from 64 to 2048
-    (the reference accepts any n_fft; 4096 would need more than the 160 KB of LDS per CU)."""
+    """The device FFT is a radix-2 kernel that keeps eight (n_fft = 4096: four) frames of one workgroup in LDS: powers of two from 64
+    to 4096 (the reference accepts any n_fft)."""
     if int(n_fft) not in SUPPORTED_N_FFT:
         raise ParameterError('n_fft={} is not supported by the HIP STFT/iSTFT: use one of {}'.format(n_fft, SUPPORTED_N_FFT))
 

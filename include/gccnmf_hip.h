@@ -59,9 +59,9 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
  *   window   [n_fft] float32 analysis window (numpy.hanning(n_fft) for the reference path)
  *   twiddle  [n_fft/2] complex: exp(-2j*pi*k/n_fft), computed in float64 on the host
  *   X, V, CC as in the geometry table; V or CC may be NULL to skip that output.
- * LIMITS (the reference accepts any size): n_fft must be a power of two in [64, 2048] -- the radix-2 kernel keeps eight
- * frames per workgroup in LDS, n_fft = 4096 would exceed the 160 KB per CU -> GCCNMF_ERR_UNSUPPORTED; other sizes
- * GCCNMF_ERR_ARG.  The same holds for gccnmf_istft_ola.  The Python layer raises ParameterError naming the sizes. */
+ * LIMITS (the reference accepts any size): n_fft must be a power of two in [64, 4096] -- the radix-2 kernel keeps eight
+ * frames per workgroup in LDS (four at n_fft = 4096); other sizes GCCNMF_ERR_ARG.  The same holds for gccnmf_istft_ola.
+ * The Python layer raises ParameterError naming the sizes. */
 int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
                        const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
 

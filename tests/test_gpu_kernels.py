@@ -115,7 +115,8 @@ def test_debug_gemm(hip, layout, M, N, Kd, batch):
 # ------------------------------------------------------------------------------------------------
 # STFT / iSTFT
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('n_fft,hop,n', [(1024, 256, 20000), (1024, 128, 6000), (512, 64, 5000), (256, 100, 3000), (2048, 512, 9000)])
+@pytest.mark.parametrize('n_fft,hop,n', [(1024, 256, 20000), (1024, 128, 6000), (512, 64, 5000), (256, 100, 3000), (2048, 512, 9000),
+                                         (4096, 1024, 30000)])      # four frames per workgroup instead of eight
 def test_stft_stereo(hip, n_fft, hop, n):
     from gcc_nmf_amd.gccNMFFunctions import computeComplexMixtureSpectrogram
     rng = np.random.RandomState(n_fft + hop)
@@ -124,6 +125,16 @@ def test_stft_stereo(hip, n_fft, hop, n):
     ref = O.computeComplexMixtureSpectrogram(x, n_fft, hop, np.hanning)
     assert X.shape == ref.shape and X.dtype == np.complex64
     assert np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_istft_n_fft_4096(hip):
+    from gcc_nmf_amd.librosaSTFT import stft, istft
+    rng = np.random.RandomState(7)
+    sig = (rng.standard_normal(40000) * 0.1).astype(np.float32)
+    S = O.stft(sig.copy(), 4096, 1024, 4096, np.hanning, center=True)
+    y, yr = istft(S, 1024, 4096, np.hanning), O.istft(S, 1024, 4096, np.hanning)
+    assert y.shape == yr.shape and np.abs(y - yr).max() < 1e-5 * np.abs(yr).max()
+    assert np.abs(stft(sig.copy(), 4096, 1024, 4096, np.hanning, center=True) - S).max() < 1e-5 * np.abs(S).max()
 
 
 def test_stft_mono_center_and_errors(hip):

@@ -166,10 +166,10 @@ def test_bench_contract_defaults_and_loud_failure_without_gpu(monkeypatch):
 
 
 def test_unsupported_fft_sizes_are_named():
-    """The reference accepts any n_fft; the HIP FFT supports powers of two from 64 to 2048 and says so."""
+    """The reference accepts any n_fft; the HIP FFT supports powers of two from 64 to 4096 and says so."""
     from gcc_nmf_amd import librosaSTFT as L
-    for n_fft in (4096, 1000, 32):
+    for n_fft in (8192, 1000, 32):
         with pytest.raises(L.ParameterError, match='not supported'):
             L.stft(np.zeros(20000, np.float32), n_fft=n_fft, hop_length=256, window=np.hanning, center=False)
     with pytest.raises(L.ParameterError, match='not supported'):
-        L.istft(np.zeros((2049, 4), np.complex64), hop_length=256, window=np.hanning)
+        L.istft(np.zeros((4097, 4), np.complex64), hop_length=256, window=np.hanning)
