@@ -155,7 +155,8 @@ class StreamingGCCNMF(object):
     """``OverlapAddProcessor.processFrames(GCCNMFProcessor.processFrames)`` (utils.py:99-116) as one device call per block:
     ``process_block((2, blockSize)) -> (2, blockSize)``, output delayed by two blocks like the reference."""
 
-    def __init__(self, processor, hopSize, blockSize, outputDelayBlocks=2):
+    def __init__(self, processor, hopSize, blockSize, outputDelayBlocks=2, use_graph=True):
+        self.use_graph = bool(use_graph)
         # outputDelayBlocks: 2 = the reference's hand-out (utils.py:116); 1 is complete when the synthesis window spans two hops
         if outputDelayBlocks not in (1, 2, 3, 4, 5, 6, 7):
             raise ValueError('outputDelayBlocks must be 1..7')
@@ -178,20 +179,50 @@ class StreamingGCCNMF(object):
 
     def process_block(self, block):
         """Host block in -> host block out.  The finished block is fetched (pinned buffer, its own event) BEFORE the tracking update
-        of the next block's target has run: that kernel only writes state the next call reads, so it stays off the latency path."""
+        of the next block's target has run: that kernel only writes state the next call reads, so it stays off the latency path.
+        The fixed launch sequence (upload, kernels, download) is captured once into a HIP graph and replayed per block."""
         if getattr(self, '_pin_in', None) is None:
             self._pin_in = torch.zeros((2, self.blockSize), dtype=torch.float32).pin_memory()
             self._pin_out = torch.zeros((2, self.blockSize), dtype=torch.float32).pin_memory()
             self._ev_out = torch.cuda.Event()
-        with torch.cuda.device(self.p.device):
+            self._graph, self._graph_key = None, None
+        p = self.p
+        with torch.cuda.device(p.device):
             self._pin_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))
-            self.block_in.copy_(self._pin_in, non_blocking=True)
-            self.p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 2, self.outputDelayBlocks)
-            self._pin_out.copy_(self.block_out, non_blocking=True)
+            # everything the captured launches depend on besides buffer contents: re-capture when one of them changes
+            key = (int(p.targetMode), bool(p.separationEnabled), bool(p.localizationEnabled), int(p.localizationWindowSize),
+                   int(p.numHUpdates), p.dW.data_ptr(), p.dTarget.data_ptr())
+            if self.use_graph and self._graph_key != key:
+                self._graph, self._graph_key = self._capture(), key
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._launch_front()
             self._ev_out.record()
-            self.p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 4, self.outputDelayBlocks)
+            p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 4, self.outputDelayBlocks)
             self._ev_out.synchronize()
         return self._pin_out.numpy().copy()
+
+    def _launch_front(self):
+        self.block_in.copy_(self._pin_in, non_blocking=True)
+        self.p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 2, self.outputDelayBlocks)
+        self._pin_out.copy_(self.block_out, non_blocking=True)
+
+    def _capture(self):
+        """upload -> kernels (all but the tracking update) -> download as one HIP graph; None if capture is not possible here."""
+        try:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            state = [t.clone() for t in (self.in_ring, self.out_ring, self.p.dHist, self.p.dHistPos, self.p.dTarget)]
+            with torch.cuda.graph(g):
+                self._launch_front()
+            # capture does not execute on ROCm, but restore the state anyway in case a runtime runs the body once
+            for t, s0 in zip((self.in_ring, self.out_ring, self.p.dHist, self.p.dHistPos, self.p.dTarget), state):
+                t.copy_(s0)
+            torch.cuda.synchronize()
+            return g
+        except Exception:
+            return None
 
     def process_stream(self, stereoSamples):
         """(2, n) -> (2, n_blocks*blockSize); the whole signal is uploaded once, every block is one device call."""

@@ -204,3 +204,25 @@ def test_low_latency_stream_is_the_identity_one_block_late_when_separation_is_of
         warnings.simplefilter('ignore')
         yr = np.concatenate([ola.processFrames(xs[:, b * hop:(b + 1) * hop], ora.processFrames) for b in range(60)], axis=1)
     assert np.abs(yd - yr).max() < 5e-4 * np.abs(xs).max()
+
+
+def test_graph_replay_equals_direct_launches():
+    """process_block replays a captured HIP graph (upload, kernels, download); it must produce exactly what the direct launches do,
+    also across a parameter change that forces a re-capture."""
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF
+    ws, hop, K, D = 512, 64, 128, 64
+    W = R.make_rt_dictionary(3, ws // 2 + 1, K)
+    x = O.synthetic_mixture(9, numSamples=80 * hop, delays=(-3, 1, 4))
+    outs = []
+    for use_graph in (False, True):
+        p = GCCNMFProcessor(16000, ws, 1, {'Pretrained': {K: W}}, 'Pretrained', K, 1, 0.1, True, 6, numTDOAs=D)
+        p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+        s = StreamingGCCNMF(p, hop, hop, use_graph=use_graph)
+        ys = []
+        for b in range(80):
+            if b == 40:
+                p.targetMode = 0                       # boxcar: a different launch argument -> re-capture
+            ys.append(s.process_block(x[:, b * hop:(b + 1) * hop]))
+        assert (s._graph is not None) == use_graph
+        outs.append(np.concatenate(ys, axis=1))
+    assert np.array_equal(outs[0], outs[1])
