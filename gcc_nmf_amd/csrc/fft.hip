@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 // K = 1024 in the two-kernel form).  A workgroup owns the output samples of G = ISTFT_SUB * ISTFT_TB consecutive hops of one
 // signal pair; it transforms frames t0-H .. t0+G-1 (H = ceil(N/hop)-1 halo frames that also reach into its range: 9 % more
 // spectrogram reads at N/hop = 4) in ascending sub-batches of ISTFT_TB frames and adds each frame into a sliding LDS accumulator
-// in ASCENDING frame order, every sample starting from 0 -- the order librosaSTFT.py:275-281 accumulates in; the result equals that
-// of istft_frames_kernel + istft_ola_kernel to the last bit or two (the accumulation is identical, but the compiler contracts the
-// FFT butterflies of the two kernels into fmas differently: measured max 3.7e-9 at |y| ~ 0.06).  grid = batch * (nsig/2) * ceil(T / G).
+// in ASCENDING frame order, every sample starting from 0 -- the order librosaSTFT.py:275-281 accumulates in; the result is bit for
+// bit that of istft_frames_kernel + istft_ola_kernel (no fma contraction in this file, same accumulation).
+// grid = batch * (nsig/2) * ceil(T / G).
 #ifndef ISTFT_TB
 #define ISTFT_TB 4
 #endif
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
                 if (n >= 0 && n < N && fs + tb < t_end) {
                     const float2 v = z[tb * zstride + n];
                     const float w = window[n];
-                    // (explicitly rounded products and sums: the reference adds whole frames, no fma across the window product)
-                    va = __fadd_rn(va, __fmul_rn(w, __fmul_rn(v.x, invN)));
-                    vb = __fadd_rn(vb, __fmul_rn(w, __fmul_rn(v.y, invN)));
+                    // (no fma across the window product: this file is compiled with -ffp-contract=off; the reference adds whole frames)
+                    va = va + w * (v.x * invN);
+                    vb = vb + w * (v.y * invN);
                 }
             }
             acc_a[i] = va;

@@ -7,6 +7,9 @@
 #define FFT_NT 256
 #define FFT_ZPAD 9   // row padding (in complex elements) of the per-frame LDS buffers
 
+// fft.hip is compiled with -ffp-contract=off (Makefile): the compiler's own fma contraction differs from kernel to kernel, and the
+// offline kernels that share this FFT must produce the same bits (the fused and the two-kernel inverse STFT are chosen by launch
+// size).  HIP's __fmul_rn / __fadd_rn are plain operators to the optimiser and do not prevent it.
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }

@@ -52,22 +52,43 @@ __global__ __launch_bounds__(64) void pick_peaks_kernel(const double* __restrict
     __syncthreads();
     for (int i = threadIdx.x; i < D; i += 64) is_peak[i] = (i > 0 && i < D - 1 && v[i] > v[i - 1] && v[i] > v[i + 1]) ? 1 : 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int found = 0;
-        int* out = tdoa_idx + (long)b * S;
-        for (int s = 0; s < S; ++s) {
-            int best = -1;
-            for (int i = 1; i < D - 1; ++i)
-                if (is_peak[i] == 1 && (best < 0 || v[i] > v[best])) best = i;
-            if (best < 0) break;
-            is_peak[best] = 2;
-            ++found;
+    // top-S peaks: S rounds of a 64-lane arg-max over the peaks still standing (largest value, smallest index on ties -- the order
+    // the serial scan this replaces produced; that scan cost 33 us of a single-mixture run)
+    __shared__ int s_found;
+    if (threadIdx.x == 0) s_found = 0;
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        double bv = 0.0;
+        int bi = -1;
+        for (int i = 1 + threadIdx.x; i < D - 1; i += 64)
+            if (is_peak[i] == 1 && (bi < 0 || v[i] > bv)) {
+                bv = v[i];
+                bi = i;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
         }
+        if (bi < 0) break;                     // wave-uniform after the butterfly
+        if (threadIdx.x == 0) {
+            is_peak[bi] = 2;
+            ++s_found;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* out = tdoa_idx + (long)b * S;
         int n = 0;
         for (int i = 1; i < D - 1 && n < S; ++i)
             if (is_peak[i] == 2) out[n++] = i;
         for (; n < S; ++n) out[n] = -1;
-        status[b] = (found == S) ? 0 : 1;
+        status[b] = (s_found == S) ? 0 : 1;
     }
 }
 

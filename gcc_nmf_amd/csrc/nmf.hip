@@ -95,21 +95,25 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(float* out, int iters
 // ------------------------------------------------------------------------------------------
 // small K-vector kernels
 // ------------------------------------------------------------------------------------------
-// colsumW[k] = sum_f W[f][k]; hscale[k] = 1.   grid = batch * Kp/64, 256 threads.
+// colsumW[k] = sum_f W[f][k]; hscale[k] = 1.   grid = batch * Kp/16, 256 threads = 16 atoms x 16 row phases (one file: 64 workgroups
+// of 33-row chains instead of 16 of 129: 40 -> ~8 us).
 __global__ __launch_bounds__(256) void nmf_prepare_kernel(const float* __restrict__ W, float* __restrict__ colsumW,
                                                           float* __restrict__ hscale, int F, int Fp, int Kp) {
-    __shared__ float red[256];
-    const int chunks = Kp / 64;
+    __shared__ float red[4][16];
+    const int chunks = Kp / 16;
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int k = ch * 64 + c;
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int k = ch * 16 + c;
     const float* Wb = W + (long)b * Fp * Kp;
     float s = 0.f;
-    for (int f = q; f < F; f += 4) s += Wb[(long)f * Kp + k];
-    red[threadIdx.x] = s;
+#pragma unroll 4
+    for (int f = q; f < F; f += 16) s += Wb[(long)f * Kp + k];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if ((threadIdx.x & 63) < 16) red[wave][c] = s;
     __syncthreads();
-    if (q == 0) {
-        colsumW[(long)b * Kp + k] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
+    if (threadIdx.x < 16) {
+        colsumW[(long)b * Kp + k] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         hscale[(long)b * Kp + k] = 1.f;
     }
 }
@@ -593,7 +597,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
     const int xcd = (flags & 1) ? 0 : 1;
-    const int vec_grid = batch * (g.Kp / 64);
+    const int vec_grid = batch * (g.Kp / 16);
     switch (stage) {
         case 0:
             // R's padding (rows >= F, columns >= N) must be zero: it is a reduction operand of K2 and K4a.
@@ -678,7 +682,7 @@ int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, in
     NmfGeom g = make_geom(F, N, K);
     SharedWs w = carve_shared(workspace, g, batch);
     if (hipMemsetAsync(w.R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-    hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 64), dim3(256), 0, s, W, w.colsumW, w.hscale, g.F, g.Fp, g.Kp);
+    hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 16), dim3(256), 0, s, W, w.colsumW, w.hscale, g.F, g.Fp, g.Kp);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

@@ -165,7 +165,9 @@ class GCCNMFEngine(object):
             # windowed time frames [B][2S][T][n_fft]: only the two-kernel iSTFT needs them (allocated on first use); the default is the
             # fused inverse-transform + overlap-add pass, available while n_fft + 3 * hop <= 2048
             self.frames = None
-            self.fused_istft = self.n_fft + 3 * self.hop <= 2048
+            # (a fused workgroup transforms 35 frames in sequence: with fewer than ~256 of them the two-kernel form is the faster one --
+            # one file: 181 us fused against 42 us)
+            self.fused_istft = self.n_fft + 3 * self.hop <= 2048 and B * g.S * -(-T // 32) >= 256
             self.y = z(B, g.S, 2, self.L)
             self.pcm_in = None        # set by upload_pcm16(): the STFT then reads int16 frames directly
             self.pcm_out = None
