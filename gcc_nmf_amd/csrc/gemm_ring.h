@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     constexpr int BK = 16, BM = 128, BN = 64;
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int STG = SA + SB;                                   // floats per stage (12 KB)
-    constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);
+    constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE || EPI == EPI_DIVFIX);
     static_assert(!TAIL || A_KC, "the VALU tail row needs a reduction-contiguous A");
     static_assert(NSTAGE >= 4 && NSTAGE <= 12, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float ring_smem[];     // ring | tail row of A [nkt*16] | row scale of B [nkt*16]
@@ -319,7 +319,105 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     // the redundant pieces issued past the last k-tile are still landing; the epilogue reuses the ring as scratch
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    if constexpr (EPI == EPI_UPDH) {
+    if constexpr (EPI == EPI_DIVFIX) {
+        // Split-K with the combine folded into the launch (one file alone: W.H in kparts parts).  Every part stores its partial tile
+        // (and its share of the VALU tail row) to C + part * sC, then bumps the tile's arrival counter; the part that arrives LAST
+        // reads all kparts partials back -- its own included, so what is added does not depend on who is last -- adds them in
+        // ascending part order, exactly as nmf_div_partials_kernel does, and writes C2 = E0 / sum.  Result: bit-identical to the
+        // two-launch form, without the 5 us combine launch behind every W.H.  The counter is left at zero for the next launch.
+        // Visibility across the 8 XCD-private L2s, fix_mode 1: agent-scope fences around the counter (release before the bump, acquire
+        // before the read-back); fix_mode 2: the partials themselves are agent-scope relaxed atomic stores / loads (write-through,
+        // L2-coherent reads), ordered by completion (vmcnt) before the bump.
+        auto fix = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const int nparts = p.kparts;
+            const int rb = row0 + wave * 32 + 4 * hh;
+            const int ca = col0 + l31, cb = ca + 32;
+            const bool oka = ca < p.N, okb = cb < p.N;
+            const int cac = min(ca, p.N - 1), cbc = min(cb, p.N - 1);
+            const int tcol = min(col0 + tid, p.N - 1);
+            float tail_s = 0.f;
+            if (TAIL) {
+                if (side_wg) {
+                    ring_smem[tid] = tail_acc;
+                    __syncthreads();
+                    if (tid < BN) tail_s = (ring_smem[tid] + ring_smem[BN + tid]) + (ring_smem[2 * BN + tid] + ring_smem[3 * BN + tid]);
+                }
+            }
+            const bool tail_lane = TAIL && side_wg && tid < BN && (col0 + tid) < p.N;
+            const long tail_off = (long)p.tail_row * p.ldc + tcol;
+            float* Pm = p.C + (long)file * p.sC;
+            auto st = [&](float* q, float v) {
+                if (MODE == 2) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *q = v;
+            };
+            auto ld = [&](const float* q) -> float {
+                if (MODE == 2) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return *q;                 // after the acquire fence
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    if (oka) st(Pm + (long)row * p.ldc + ca, acc0[r]);
+                    if (okb) st(Pm + (long)row * p.ldc + cb, acc1[r]);
+                }
+            }
+            if (tail_lane) st(Pm + tail_off, tail_s);
+            // E0 (V) does not depend on the other parts: in flight while the counter is bumped
+            float va[16], vb[16], vt = 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+                va[r] = p.E0[ro + cac];
+                vb[r] = p.E0[ro + cbc];
+            }
+            if (tail_lane) vt = p.E0[tail_off];
+            if (MODE == 1) __threadfence();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* s_flag = (unsigned*)ring_smem + 320;
+            unsigned* counter = p.fix_counter + (tm * p.tiles_n + tn);
+            if (tid == 0) *s_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if ((int)*s_flag != nparts - 1) return;
+            if (MODE == 1) __threadfence();
+            float pa[4][16], pb[4][16], pt[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pt[q] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pa[q][r] = pb[q][r] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nparts) {
+                    const float* Pq = p.C + (long)q * p.sC;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+                        pa[q][r] = ld(Pq + ro + cac);
+                        pb[q][r] = ld(Pq + ro + cbc);
+                    }
+                    if (tail_lane) pt[q] = ld(Pq + tail_off);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2);
+                const float da = ((pa[0][r] + pa[1][r]) + pa[2][r]) + pa[3][r];       // absent parts add +0.0f: exact
+                const float db = ((pb[0][r] + pb[1][r]) + pb[2][r]) + pb[3][r];
+                if (row < p.M) {
+                    if (oka) p.C2[(long)row * p.ldc + ca] = va[r] / da;
+                    if (okb) p.C2[(long)row * p.ldc + cb] = vb[r] / db;
+                }
+            }
+            if (tail_lane) p.C2[tail_off] = vt / (((pt[0] + pt[1]) + pt[2]) + pt[3]);
+            if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (p.fix_mode == 2) fix(std::integral_constant<int, 2>{});
+        else fix(std::integral_constant<int, 1>{});
+    } else if constexpr (EPI == EPI_UPDH) {
         // H update with the per-row factors (lazy scale, 1 / (column sum + alpha + eps), rank-1 tail column of A) put into LDS once per
         // workgroup: the generic epilogue loads them per element and divides per element (4.0 us of a 21 us launch for one file)
         float* s_sc = ring_smem, *s_rd = ring_smem + BM, *s_ta = ring_smem + 2 * BM;
@@ -355,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     } else {
         gemm_epilogue_pair<EPI>(p, file, row0 + wave * 32 + 4 * hh, col0 + l31, acc0, acc1);
     }
-    if (TAIL) {
+    if constexpr (TAIL && EPI != EPI_DIVFIX) {
         if (side_wg) {
             ring_smem[tid] = tail_acc;
             __syncthreads();

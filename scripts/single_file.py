@@ -43,6 +43,15 @@ def run(label, reps=3):
 if '--profile' in sys.argv:
     run('default', 2)
     sys.exit(0)
+if '--fix' in sys.argv:          # how the W.H split-K parts are combined (tuning key 8), for 2 / 3 / 4 parts
+    for wh in (3, 2, 4):
+        lib.gccnmf_set_tuning(5, wh)
+        ys = []
+        for fix in (0, 1, 2):
+            lib.gccnmf_set_tuning(8, fix)
+            ys.append(run('W.H in %d parts, combine %s' % (wh, ('second launch', 'in launch (fences)', 'in launch (write-through)')[fix])))
+        print('    bit-identical waveforms: %s' % (bool(torch.equal(ys[0], ys[1])) and bool(torch.equal(ys[0], ys[2]))), flush=True)
+    sys.exit(0)
 lib.gccnmf_set_tuning(4, 0)
 y_old = run('register-staged (round 1)')
 lib.gccnmf_set_tuning(4, 1)
