@@ -50,8 +50,9 @@ enum GemmEpilogue {
     EPI_UPDH = 2,    // C[row][col] = (C[row][col]*E1[row]) * (acc / (E2[row] + alpha + eps))   (H update, :76)
     EPI_PHASE = 3,   // Cx[ic][row][t] = acc * X[c][row][t] / |X|              (:150-151)
     EPI_UPDW = 4,    // block-level: W = normalise(W * acc / rowsum(B)); the tile must own every row  (:77,:79-80)
-    EPI_DIVFIX = 5   // ring kernel, split-K only: partial tile -> C + part * sC; the LAST part to arrive at a tile adds the parts in
+    EPI_DIVFIX = 5,  // ring kernel, split-K only: partial tile -> C + part * sC; the LAST part to arrive at a tile adds the parts in
                      //   ascending order and writes C2[row][col] = E0[row][col] / sum (no separate combine launch)
+    EPI_UPDHFIX = 6  // ring kernel, split-K only: same hand-over, the last part applies EPI_UPDH to C2 in place with acc = sum of the parts
 };
 
 struct GemmArgs {

@@ -417,6 +417,92 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
         };
         if (p.fix_mode == 2) fix(std::integral_constant<int, 2>{});
         else fix(std::integral_constant<int, 1>{});
+    } else if constexpr (EPI == EPI_UPDHFIX) {
+        // The H update (K2) of one file alone as a split-K launch: 160 output tiles are 160 workgroups for 256 CUs, each a chain of 32
+        // k-tiles; cut in kparts parts every CU is busy and the chain is a third as long.  Hand-over as in EPI_DIVFIX; the last part
+        // adds the partial W^T.R tiles in ascending order, then the rank-1 reduction tail (f = F-1, still the final reduction index) and
+        // the update itself exactly as EPI_UPDH does: C2 = (C2 * E1[row]) * (acc / (E2[row] + alpha + eps)) via the row reciprocal.
+        auto fixh = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const int nparts = p.kparts;
+            float* s_sc = ring_smem, *s_rd = ring_smem + BM, *s_ta = ring_smem + 2 * BM;
+            if (tid < BM) {
+                const int row = min(row0 + tid, p.M - 1);
+                s_sc[tid] = p.E1 ? p.E1[row] : 1.f;
+                s_rd[tid] = 1.0f / (p.E2[row] + p.alpha + p.eps);
+                s_ta[tid] = p.ktailA ? p.ktailA[row] : 0.f;
+            }
+            const int rb = row0 + wave * 32 + 4 * hh;
+            const int ca = col0 + l31, cb = ca + 32;
+            const bool oka = ca < p.N, okb = cb < p.N;
+            const int cac = min(ca, p.N - 1), cbc = min(cb, p.N - 1);
+            const float ba = p.ktailA ? p.ktailB[cac] : 0.f, bb = p.ktailA ? p.ktailB[cbc] : 0.f;
+            float* Pm = p.C + (long)file * p.sC;
+            auto st = [&](float* q, float v) {
+                if (MODE == 2) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *q = v;
+            };
+            auto ld = [&](const float* q) -> float {
+                if (MODE == 2) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return *q;                 // after the acquire fence
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    if (oka) st(Pm + (long)row * p.ldc + ca, acc0[r]);
+                    if (okb) st(Pm + (long)row * p.ldc + cb, acc1[r]);
+                }
+            }
+            // the tile of H this launch will rewrite is touched by nobody but the last part: its old values can be in flight now
+            float ha[16], hb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+                ha[r] = p.C2[ro + cac];
+                hb[r] = p.C2[ro + cbc];
+            }
+            if (MODE == 1) __threadfence();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* s_flag = (unsigned*)ring_smem + 3 * BM + 16;
+            unsigned* counter = p.fix_counter + (tm * p.tiles_n + tn);
+            if (tid == 0) *s_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if ((int)*s_flag != nparts - 1) return;
+            if (MODE == 1) __threadfence();
+            float pa[4][16], pb[4][16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pa[q][r] = pb[q][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nparts) {
+                    const float* Pq = p.C + (long)q * p.sC;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
+                        pa[q][r] = ld(Pq + ro + cac);
+                        pb[q][r] = ld(Pq + ro + cbc);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2), row = row0 + lr;
+                const float sc = s_sc[lr], rd = s_rd[lr], ta = s_ta[lr];
+                const float ua = fmaf(ta, ba, ((pa[0][r] + pa[1][r]) + pa[2][r]) + pa[3][r]);      // absent parts add +0.0f: exact
+                const float ub = fmaf(ta, bb, ((pb[0][r] + pb[1][r]) + pb[2][r]) + pb[3][r]);
+                if (row < p.M) {
+                    if (oka) p.C2[(long)row * p.ldc + ca] = (ha[r] * sc) * (ua * rd);
+                    if (okb) p.C2[(long)row * p.ldc + cb] = (hb[r] * sc) * (ub * rd);
+                }
+            }
+            if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (p.fix_mode == 2) fixh(std::integral_constant<int, 2>{});
+        else fixh(std::integral_constant<int, 1>{});
     } else if constexpr (EPI == EPI_UPDH) {
         // H update with the per-row factors (lazy scale, 1 / (column sum + alpha + eps), rank-1 tail column of A) put into LDS once per
         // workgroup: the generic epilogue loads them per element and divides per element (4.0 us of a 21 us launch for one file)

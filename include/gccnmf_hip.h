@@ -49,7 +49,9 @@ int gccnmf_version(void);
  * key 4: 1 (default) = small launches on the LDS-DMA ring kernel (csrc/gemm_ring.h), 0 = register-staged.  keys 5 / 6: split-K parts
  * of W.H / R.H^T when ONE mixture is processed alone (1..4).  key 7: ring depth (0 auto, 6, 10).  key 8: how the split-K parts of
  * W.H are combined -- 0 = a second launch (nmf_div_partials_kernel), 1 / 2 = inside the GEMM launch by the part that arrives last
- * at a tile (1: agent-scope fences, 2: write-through partial stores; bit-identical results either way), -1 = the default. */
+ * at a tile (1: agent-scope fences, 2: write-through partial stores; bit-identical results either way), -1 = the default.
+ * key 9: split-K parts of the H update (W^T.R) when one mixture is processed alone (1 = unsplit, 2..4; combined inside the launch
+ * as for key 8), -1 = the default. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */

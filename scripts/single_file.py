@@ -51,6 +51,15 @@ if '--fix' in sys.argv:          # how the W.H split-K parts are combined (tunin
             lib.gccnmf_set_tuning(8, fix)
             ys.append(run('W.H in %d parts, combine %s' % (wh, ('second launch', 'in launch (fences)', 'in launch (write-through)')[fix])))
         print('    bit-identical waveforms: %s' % (bool(torch.equal(ys[0], ys[1])) and bool(torch.equal(ys[0], ys[2]))), flush=True)
+    lib.gccnmf_set_tuning(5, 3)
+    lib.gccnmf_set_tuning(8, 0)
+    ys = [run('baseline again: W.H in 3 parts, second launch, H update unsplit')]
+    for fix in (0, 1, 2):         # ... and the H update as a split-K launch with the in-launch combine (tuning key 9)
+        lib.gccnmf_set_tuning(8, fix)
+        for hs in (2, 3, 4):
+            lib.gccnmf_set_tuning(9, hs)
+            y = run('W.H combine mode %d, H update in %d parts' % (fix, hs))
+            print('    waveform rms vs unsplit H update: %.2e' % float(((y - ys[0]) ** 2).mean().sqrt()), flush=True)
     sys.exit(0)
 lib.gccnmf_set_tuning(4, 0)
 y_old = run('register-staged (round 1)')
