@@ -40,6 +40,9 @@ def run(label, reps=3):
     return e.y.clone()
 
 
+for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE=8=1,9=3
+    key, val = [int(v) for v in kv.split('=')]
+    assert lib.gccnmf_set_tuning(key, val) == 0, kv
 if '--profile' in sys.argv:
     run('default', 2)
     sys.exit(0)
