@@ -49,10 +49,7 @@ enum GemmEpilogue {
     EPI_DIV = 1,     // C[row][col] = E0[row][col] / acc                      (R = V / (W.H),  :76/:77)
     EPI_UPDH = 2,    // C[row][col] = (C[row][col]*E1[row]) * (acc / (E2[row] + alpha + eps))   (H update, :76)
     EPI_PHASE = 3,   // Cx[ic][row][t] = acc * X[c][row][t] / |X|              (:150-151)
-    EPI_UPDW = 4,    // block-level: W = normalise(W * acc / rowsum(B)); the tile must own every row  (:77,:79-80)
-    EPI_DIVFIX = 5,  // ring kernel, split-K only: partial tile -> C + part * sC; the LAST part to arrive at a tile adds the parts in
-                     //   ascending order and writes C2[row][col] = E0[row][col] / sum (no separate combine launch)
-    EPI_UPDHFIX = 6  // ring kernel, split-K only: same hand-over, the last part applies EPI_UPDH to C2 in place with acc = sum of the parts
+    EPI_UPDW = 4     // block-level: W = normalise(W * acc / rowsum(B)); the tile must own every row  (:77,:79-80)
 };
 
 struct GemmArgs {
@@ -79,9 +76,6 @@ struct GemmArgs {
     float* C;
     long sC;
     int ldc;
-    float* C2;                 // EPI_DIVFIX: the combined output (same pitch as C)
-    unsigned* fix_counter;     // EPI_DIVFIX: one arrival counter per output tile, zero before the launch, left zero by it
-    int fix_mode;              // EPI_DIVFIX: 1 = agent-scope fences around the counter, 2 = agent-scope (write-through) stores / loads of the partials
     const float* E0;
     long sE0;
     const float* E1;

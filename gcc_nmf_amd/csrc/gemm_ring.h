@@ -24,6 +24,10 @@
 #include <type_traits>
 #include "gemm_dma.h"
 
+#ifndef RING_EARLY_FINISH
+#define RING_EARLY_FINISH 1
+#endif
+
 template <int N>
 __device__ __forceinline__ void gemm_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     constexpr int BK = 16, BM = 128, BN = 64;
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int STG = SA + SB;                                   // floats per stage (12 KB)
-    constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE || EPI == EPI_DIVFIX);
+    constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);
     static_assert(!TAIL || A_KC, "the VALU tail row needs a reduction-contiguous A");
     static_assert(NSTAGE >= 4 && NSTAGE <= 12, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float ring_smem[];     // ring | tail row of A [nkt*16] | row scale of B [nkt*16]
@@ -121,11 +125,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
             }
         }
         if (SCALE) {
-            if (bscale != nullptr) {
+            if (bscale != nullptr) {      // (no scale pending, K3: the loop copy without the multiplies runs, below)
                 for (int pc = wave; pc * 256 < nkt * BK; pc += 4) gemm_dma16(bscale, min(1024u * pc + 16u * lane, last), lds_scale + 1024u * pc);
-            } else {
-                for (int k = tid; k < nkt * BK; k += 256) ring_smem[NSTAGE * STG + nside + k] = 1.f;     // no lazy scale pending (K3)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
     }
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
 
     // The reads of one k-tile in six parts, dealt out between the MFMAs of the previous tile.  DT (compile time): this workgroup
     // carries the tail row / the row sums.
-    auto read_part = [&](auto dt_c, Frags& f, const unsigned sb, const int kt, const int part) {
+    auto read_part = [&](auto dt_c, auto sc_c, Frags& f, const unsigned sb, const int kt, const int part) {
         constexpr bool DT = decltype(dt_c)::value;
+        constexpr bool SC = SCALE && decltype(sc_c)::value;      // a lazy row scale of B is pending (K1), not just possible
         const int q = part >> 1;
         if (part < 4) {
             const unsigned ao = sb + (q ? oA1 : oA0), bo = sb + (q ? oB1 : oB0);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
                     f.b2[q][2] = gemm_lds_read2_b32<2 * BN, 2 * BN + 32>(bo);
                     f.b2[q][3] = gemm_lds_read2_b32<3 * BN, 3 * BN + 32>(bo);
                 }
-                if (SCALE) f.sc[q] = gemm_lds_read_b128<0>(lds_scale + 4u * (unsigned)(kt * BK + 4 * (2 * q + hh)));
+                if (SC) f.sc[q] = gemm_lds_read_b128<0>(lds_scale + 4u * (unsigned)(kt * BK + 4 * (2 * q + hh)));
             }
         } else if (part == 4) {
             if (TAIL && DT) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
                 } else {
                     f.tbxy = gemm_lds_read2_b32<0 * BN, 1 * BN>(sb + oTB);
                     f.tbzw = gemm_lds_read2_b32<2 * BN, 3 * BN>(sb + oTB);
-                    if (SCALE) f.ts4 = gemm_lds_read_b128<0>(lds_scale + 4u * (unsigned)(kt * BK + 4 * tg));
+                    if (SC) f.ts4 = gemm_lds_read_b128<0>(lds_scale + 4u * (unsigned)(kt * BK + 4 * tg));
                 }
             }
         } else if (part == 5) {
@@ -205,8 +207,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
         }
     };
     // "the fragments have landed": wait, tie every destination, apply the lazy row scale of B as one burst
-    auto finish_reads = [&](auto dt_c, Frags& f) {
+    auto finish_reads = [&](auto dt_c, auto sc_c, Frags& f) {
         constexpr bool DT = decltype(dt_c)::value;
+        constexpr bool SC = SCALE && decltype(sc_c)::value;
         gemm_wait_lds();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gemm_tie(f.b2[q][e]);
             }
-            if (SCALE) {
+            if (SC) {
                 gemm_tie(f.sc[q]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f.b2[q][e] *= f.sc[q][e];              // fl(H * s): v_pk_mul_f32
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
                 gemm_tie(f.tbxy);
                 gemm_tie(f.tbzw);
                 f.tb4 = gemm_f32x4{f.tbxy.x, f.tbxy.y, f.tbzw.x, f.tbzw.y};
-                if (SCALE) {
+                if (SC) {
                     gemm_tie(f.ts4);
                     f.tb4 *= f.ts4;
                 }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     //   16 MFMAs of tile kt, with the reads of tile kt+1 (other register set) and the LDS-DMA pieces of tile kt+NSTAGE-1 dealt out
     //   between them (into the stage of tile kt-1, which every wave finished reading before the last barrier) | side FMAs |
     //   fragments of tile kt+1 landed + scaled | wait until tile kt+2 has landed | barrier
-    auto step = [&](auto dt_c, Frags& cur, Frags& nxt, const int kt, const int stage) {
+    auto step = [&](auto dt_c, auto sc_c, Frags& cur, Frags& nxt, const int kt, const int stage) {
         constexpr bool DT = decltype(dt_c)::value;
         const unsigned sbn = lds0 + 4u * (unsigned)(((stage + 1 == NSTAGE) ? 0 : stage + 1) * STG);
         const int refill = (stage == 0) ? NSTAGE - 1 : stage - 1;
@@ -268,7 +271,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
                 if (slot == 0) gemm_dma16(Ak, offA[0], dst + 4 * ((wave * 2 + 0) * 256));
                 if (slot == 1) gemm_dma16(Ak, offA[1], dst + 4 * ((wave * 2 + 1) * 256));
                 if (slot == 2) gemm_dma16(Bk, offB, dst + 4 * (SA + wave * 256));
-                if (slot < 6) read_part(dt_c, nxt, sbn, ktn, slot);              // tile kt+1 -> the other register set
+                if (slot < 6) read_part(dt_c, sc_c, nxt, sbn, ktn, slot);        // tile kt+1 -> the other register set
+                // its fragments have landed by now (the last read went out two MFMAs ago): tie them and apply the lazy scale while the
+                // matrix pipe still has four MFMAs of this tile to issue, not in the gap before the barrier
+                if (RING_EARLY_FINISH && slot == 6) finish_reads(dt_c, sc_c, nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -282,36 +288,43 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
             if (do_rowsum) rowsum_acc += (cur.rs4.x + cur.rs4.y) + (cur.rs4.z + cur.rs4.w);
         }
         __builtin_amdgcn_sched_barrier(0);
-        finish_reads(dt_c, nxt);
+        if (!RING_EARLY_FINISH) finish_reads(dt_c, sc_c, nxt);
         __builtin_amdgcn_sched_barrier(0);
         // tile kt+2 has landed (pieces of this wave; the barrier extends it to everyone's), and every wave is past its reads of tile kt+1
         gemm_wait_vmcnt<3 * (NSTAGE - 3)>();
         asm volatile("s_barrier" ::: "memory");
     };
 
-    auto main_loop = [&](auto dt_c) {
+    auto main_loop = [&](auto dt_c, auto sc_c) {
         // tiles 0 and 1 landed and visible (the plain LDS stores of the prologue too); fragments of tile 0
         gemm_wait_vmcnt<3 * (NSTAGE - 3)>();
         asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-        for (int part = 0; part < 6; ++part) read_part(dt_c, fr0, lds0, 0, part);
-        finish_reads(dt_c, fr0);
+        for (int part = 0; part < 6; ++part) read_part(dt_c, sc_c, fr0, lds0, 0, part);
+        finish_reads(dt_c, sc_c, fr0);
         if (p.trace && tid == 0) {
             p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
             p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
         }
         int stage = 0;
         for (int kt = 0; kt < nkt; kt += 2) {
-            step(dt_c, fr0, fr1, kt, stage);
+            step(dt_c, sc_c, fr0, fr1, kt, stage);
             stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
             if (kt + 1 < nkt) {
-                step(dt_c, fr1, fr0, kt + 1, stage);
+                step(dt_c, sc_c, fr1, fr0, kt + 1, stage);
                 stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
             }
         }
     };
-    if ((TAIL || B_KC) && side_wg) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
+    // loop copies, chosen once per workgroup: with / without the side work of the row-0 tiles, with / without the lazy-scale multiplies
+    const bool dt = (TAIL || B_KC) && side_wg;
+    if (SCALE && bscale != nullptr) {
+        if (dt) main_loop(std::true_type{}, std::true_type{});
+        else main_loop(std::false_type{}, std::true_type{});
+    } else {
+        if (dt) main_loop(std::true_type{}, std::false_type{});
+        else main_loop(std::false_type{}, std::false_type{});
+    }
     if (p.trace && tid == 0) {
         p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
         p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
@@ -319,232 +332,96 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
     // the redundant pieces issued past the last k-tile are still landing; the epilogue reuses the ring as scratch
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    if constexpr (EPI == EPI_DIVFIX) {
-        // Split-K with the combine folded into the launch (one file alone: W.H in kparts parts).  Every part stores its partial tile
-        // (and its share of the VALU tail row) to C + part * sC, then bumps the tile's arrival counter; the part that arrives LAST
-        // reads all kparts partials back -- its own included, so what is added does not depend on who is last -- adds them in
-        // ascending part order, exactly as nmf_div_partials_kernel does, and writes C2 = E0 / sum.  Result: bit-identical to the
-        // two-launch form, without the 5 us combine launch behind every W.H.  The counter is left at zero for the next launch.
-        // Visibility across the 8 XCD-private L2s, fix_mode 1: agent-scope fences around the counter (release before the bump, acquire
-        // before the read-back); fix_mode 2: the partials themselves are agent-scope relaxed atomic stores / loads (write-through,
-        // L2-coherent reads), ordered by completion (vmcnt) before the bump.
-        auto fix = [&](auto mode_c) {
-            constexpr int MODE = decltype(mode_c)::value;
-            const int nparts = p.kparts;
-            const int rb = row0 + wave * 32 + 4 * hh;
-            const int ca = col0 + l31, cb = ca + 32;
-            const bool oka = ca < p.N, okb = cb < p.N;
-            const int cac = min(ca, p.N - 1), cbc = min(cb, p.N - 1);
-            const int tcol = min(col0 + tid, p.N - 1);
-            float tail_s = 0.f;
-            if (TAIL) {
-                if (side_wg) {
-                    ring_smem[tid] = tail_acc;
-                    __syncthreads();
-                    if (tid < BN) tail_s = (ring_smem[tid] + ring_smem[BN + tid]) + (ring_smem[2 * BN + tid] + ring_smem[3 * BN + tid]);
-                }
-            }
-            const bool tail_lane = TAIL && side_wg && tid < BN && (col0 + tid) < p.N;
-            const long tail_off = (long)p.tail_row * p.ldc + tcol;
-            float* Pm = p.C + (long)file * p.sC;
-            auto st = [&](float* q, float v) {
-                if (MODE == 2) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *q = v;
-            };
-            auto ld = [&](const float* q) -> float {
-                if (MODE == 2) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return *q;                 // after the acquire fence
-            };
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb + (r & 3) + 8 * (r >> 2);
-                if (row < p.M) {
-                    if (oka) st(Pm + (long)row * p.ldc + ca, acc0[r]);
-                    if (okb) st(Pm + (long)row * p.ldc + cb, acc1[r]);
-                }
-            }
-            if (tail_lane) st(Pm + tail_off, tail_s);
-            // E0 (V) does not depend on the other parts: in flight while the counter is bumped
-            float va[16], vb[16], vt = 1.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
-                va[r] = p.E0[ro + cac];
-                vb[r] = p.E0[ro + cbc];
-            }
-            if (tail_lane) vt = p.E0[tail_off];
-            if (MODE == 1) __threadfence();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            unsigned* s_flag = (unsigned*)ring_smem + 320;
-            unsigned* counter = p.fix_counter + (tm * p.tiles_n + tn);
-            if (tid == 0) *s_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if ((int)*s_flag != nparts - 1) return;
-            if (MODE == 1) __threadfence();
-            float pa[4][16], pb[4][16], pt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pt[q] = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pa[q][r] = pb[q][r] = 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < nparts) {
-                    const float* Pq = p.C + (long)q * p.sC;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
-                        pa[q][r] = ld(Pq + ro + cac);
-                        pb[q][r] = ld(Pq + ro + cbc);
-                    }
-                    if (tail_lane) pt[q] = ld(Pq + tail_off);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb + (r & 3) + 8 * (r >> 2);
-                const float da = ((pa[0][r] + pa[1][r]) + pa[2][r]) + pa[3][r];       // absent parts add +0.0f: exact
-                const float db = ((pb[0][r] + pb[1][r]) + pb[2][r]) + pb[3][r];
-                if (row < p.M) {
-                    if (oka) p.C2[(long)row * p.ldc + ca] = va[r] / da;
-                    if (okb) p.C2[(long)row * p.ldc + cb] = vb[r] / db;
-                }
-            }
-            if (tail_lane) p.C2[tail_off] = vt / (((pt[0] + pt[1]) + pt[2]) + pt[3]);
-            if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (p.fix_mode == 2) fix(std::integral_constant<int, 2>{});
-        else fix(std::integral_constant<int, 1>{});
-    } else if constexpr (EPI == EPI_UPDHFIX) {
-        // The H update (K2) of one file alone as a split-K launch: 160 output tiles are 160 workgroups for 256 CUs, each a chain of 32
-        // k-tiles; cut in kparts parts every CU is busy and the chain is a third as long.  Hand-over as in EPI_DIVFIX; the last part
-        // adds the partial W^T.R tiles in ascending order, then the rank-1 reduction tail (f = F-1, still the final reduction index) and
-        // the update itself exactly as EPI_UPDH does: C2 = (C2 * E1[row]) * (acc / (E2[row] + alpha + eps)) via the row reciprocal.
-        auto fixh = [&](auto mode_c) {
-            constexpr int MODE = decltype(mode_c)::value;
-            const int nparts = p.kparts;
-            float* s_sc = ring_smem, *s_rd = ring_smem + BM, *s_ta = ring_smem + 2 * BM;
-            if (tid < BM) {
-                const int row = min(row0 + tid, p.M - 1);
-                s_sc[tid] = p.E1 ? p.E1[row] : 1.f;
-                s_rd[tid] = 1.0f / (p.E2[row] + p.alpha + p.eps);
-                s_ta[tid] = p.ktailA ? p.ktailA[row] : 0.f;
-            }
-            const int rb = row0 + wave * 32 + 4 * hh;
-            const int ca = col0 + l31, cb = ca + 32;
-            const bool oka = ca < p.N, okb = cb < p.N;
-            const int cac = min(ca, p.N - 1), cbc = min(cb, p.N - 1);
-            const float ba = p.ktailA ? p.ktailB[cac] : 0.f, bb = p.ktailA ? p.ktailB[cbc] : 0.f;
-            float* Pm = p.C + (long)file * p.sC;
-            auto st = [&](float* q, float v) {
-                if (MODE == 2) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *q = v;
-            };
-            auto ld = [&](const float* q) -> float {
-                if (MODE == 2) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return *q;                 // after the acquire fence
-            };
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb + (r & 3) + 8 * (r >> 2);
-                if (row < p.M) {
-                    if (oka) st(Pm + (long)row * p.ldc + ca, acc0[r]);
-                    if (okb) st(Pm + (long)row * p.ldc + cb, acc1[r]);
-                }
-            }
-            // the tile of H this launch will rewrite is touched by nobody but the last part: its old values can be in flight now
-            float ha[16], hb[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
-                ha[r] = p.C2[ro + cac];
-                hb[r] = p.C2[ro + cbc];
-            }
-            if (MODE == 1) __threadfence();
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            unsigned* s_flag = (unsigned*)ring_smem + 3 * BM + 16;
-            unsigned* counter = p.fix_counter + (tm * p.tiles_n + tn);
-            if (tid == 0) *s_flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if ((int)*s_flag != nparts - 1) return;
-            if (MODE == 1) __threadfence();
-            float pa[4][16], pb[4][16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pa[q][r] = pb[q][r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < nparts) {
-                    const float* Pq = p.C + (long)q * p.sC;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long ro = (long)min(rb + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
-                        pa[q][r] = ld(Pq + ro + cac);
-                        pb[q][r] = ld(Pq + ro + cbc);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2), row = row0 + lr;
-                const float sc = s_sc[lr], rd = s_rd[lr], ta = s_ta[lr];
-                const float ua = fmaf(ta, ba, ((pa[0][r] + pa[1][r]) + pa[2][r]) + pa[3][r]);      // absent parts add +0.0f: exact
-                const float ub = fmaf(ta, bb, ((pb[0][r] + pb[1][r]) + pb[2][r]) + pb[3][r]);
-                if (row < p.M) {
-                    if (oka) p.C2[(long)row * p.ldc + ca] = (ha[r] * sc) * (ua * rd);
-                    if (okb) p.C2[(long)row * p.ldc + cb] = (hb[r] * sc) * (ub * rd);
-                }
-            }
-            if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        if (p.fix_mode == 2) fixh(std::integral_constant<int, 2>{});
-        else fixh(std::integral_constant<int, 1>{});
-    } else if constexpr (EPI == EPI_UPDH) {
-        // H update with the per-row factors (lazy scale, 1 / (column sum + alpha + eps), rank-1 tail column of A) put into LDS once per
-        // workgroup: the generic epilogue loads them per element and divides per element (4.0 us of a 21 us launch for one file)
-        float* s_sc = ring_smem, *s_rd = ring_smem + BM, *s_ta = ring_smem + 2 * BM;
-        if (tid < BM) {
-            const int row = min(row0 + tid, p.M - 1);
-            s_sc[tid] = p.E1 ? p.E1[file * p.sE1 + row] : 1.f;
-            s_rd[tid] = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
-            s_ta[tid] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
-        }
-        __syncthreads();
-        const int ca = col0 + l31, cb = ca + 32;
-        const bool oka = ca < p.N, okb = cb < p.N;
-        const float ba = p.ktailA ? p.ktailB[file * p.s_ktailB + min(ca, p.N - 1)] : 0.f;
-        const float bb = p.ktailA ? p.ktailB[file * p.s_ktailB + min(cb, p.N - 1)] : 0.f;
-        float* Cf = p.C + file * p.sC;
-        float ha[16], hb[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                     // every load first (in-place update: the compiler must not interleave)
-            const long ro = (long)min(row0 + wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc;
-            ha[r] = Cf[ro + min(ca, p.N - 1)];
-            hb[r] = Cf[ro + min(cb, p.N - 1)];
-        }
+    // Epilogue scratch in the (now free) ring: the output tile as a [128][TP] image, then 3 x 128 per-row factors, then 256 floats for
+    // the tail-row reduction.  Why an image: in the MFMA accumulator layout a lane owns 32 scattered dwords (32 predicated dword
+    // stores, and 32 dword loads for the in-place H update); turned through LDS the tile is 8 float4 per lane, rows i * 16 + tid / 16,
+    // columns 4 * (tid % 16).  Measured on one file (scripts/ktrace_single.py): epilogue of the H update 4.3 -> 3.3 us (with its
+    // loads reordered into one round trip), of a plain store 1.3 -> 1.2 us -- what is left is memory round trips, not instructions.
+    constexpr int TP = 68;                                        // pitch: 4 rows apart (the two lane halves) is 16 banks apart
+    float* const s_tile = ring_smem;
+    float* const s_rows = ring_smem + BM * TP;
+    float* const s_red = s_rows + 3 * BM;
+    static_assert(BM * TP + 3 * BM + 256 <= 4 * STG, "epilogue scratch must fit the ring");
+    const int frow = tid >> 4, fc = 4 * (tid & 15), fcol = col0 + fc;
+    auto tile_to_lds = [&]() {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int lr = wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2), row = row0 + lr;
-            const float sc = s_sc[lr], rd = s_rd[lr], ta = s_ta[lr];
-            const float ua = fmaf(ta, ba, acc0[r]), ub = fmaf(ta, bb, acc1[r]);     // last reduction index, in chain order
-            if (row < p.M) {
-                if (oka) Cf[(long)row * p.ldc + ca] = (ha[r] * sc) * (ua * rd);
-                if (okb) Cf[(long)row * p.ldc + cb] = (hb[r] * sc) * (ub * rd);
+            const int lr = wave * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+            s_tile[lr * TP + l31] = acc0[r];
+            s_tile[lr * TP + 32 + l31] = acc1[r];
+        }
+        __syncthreads();
+    };
+
+    if constexpr (EPI == EPI_UPDH) {
+        // H update, in place: every global load first -- the old tile of H (8 float4 per lane in the image layout), the per-row factors
+        // (lazy scale, 1 / (column sum + alpha + eps), rank-1 tail column of A; one row per thread, published through LDS) and the
+        // tail row of B -- all in flight together with the turn of the accumulators through LDS; one barrier; then arithmetic and stores.
+        float* Cf = p.C + file * p.sC;
+        gemm_f32x4 h4[8], kb4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h4[i] = *(const gemm_f32x4*)(Cf + (long)min(row0 + i * 16 + frow, p.M - 1) * p.ldc + fcol);
+        if (p.ktailA) kb4 = *(const gemm_f32x4*)(p.ktailB + file * p.s_ktailB + fcol);
+        if (tid < BM) {
+            const int row = min(row0 + tid, p.M - 1);
+            s_rows[tid] = p.E1 ? p.E1[file * p.sE1 + row] : 1.f;
+            s_rows[BM + tid] = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
+            s_rows[2 * BM + tid] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
+        }
+        tile_to_lds();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = i * 16 + frow, row = row0 + lr;
+            const gemm_f32x4 a = *(const gemm_f32x4*)(s_tile + lr * TP + fc);
+            const float sc = s_rows[lr], rd = s_rows[BM + lr], ta = s_rows[2 * BM + lr];
+            // last reduction index, in chain order; columns >= N: H is zero there and stays zero
+            const float ux = fmaf(ta, kb4.x, a.x), uy = fmaf(ta, kb4.y, a.y), uz = fmaf(ta, kb4.z, a.z), uw = fmaf(ta, kb4.w, a.w);
+            const gemm_f32x4 o = {(h4[i].x * sc) * (ux * rd), fcol + 1 < p.N ? (h4[i].y * sc) * (uy * rd) : 0.f,
+                                  fcol + 2 < p.N ? (h4[i].z * sc) * (uz * rd) : 0.f, fcol + 3 < p.N ? (h4[i].w * sc) * (uw * rd) : 0.f};
+            if (row < p.M && fcol < p.N) *(gemm_f32x4*)(Cf + (long)row * p.ldc + fcol) = o;
+        }
+    } else if constexpr (EPI == EPI_STORE) {
+        float* Cf = p.C + file * p.sC;
+        if (((p.ldc & 3) | (int)(((size_t)Cf >> 2) & 3)) == 0) {      // float4-addressable output (every NMF / GCC-NMF launch): image layout
+            tile_to_lds();
+            gemm_f32x4 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *(const gemm_f32x4*)(s_tile + (i * 16 + frow) * TP + fc);
+            if (p.ktailA) {   // last reduction index as one fmaf per element, in chain order (it is the final k)
+                const float* __restrict__ tb = p.ktailB + file * p.s_ktailB;
+                const gemm_f32x4 b = {tb[min(fcol, p.N - 1)], tb[min(fcol + 1, p.N - 1)], tb[min(fcol + 2, p.N - 1)], tb[min(fcol + 3, p.N - 1)]};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ta = p.ktailA[file * p.s_ktailA + min(row0 + i * 16 + frow, p.M - 1)];
+                    a[i] = gemm_f32x4{fmaf(ta, b.x, a[i].x), fmaf(ta, b.y, a[i].y), fmaf(ta, b.z, a[i].z), fmaf(ta, b.w, a[i].w)};
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = row0 + i * 16 + frow;
+                float* q = Cf + (long)row * p.ldc + fcol;
+                if (row < p.M) {
+                    if (fcol + 3 < p.N) {
+                        *(gemm_f32x4*)q = a[i];
+                    } else {          // ragged last column tile: nothing beyond column N - 1 is written
+                        if (fcol < p.N) q[0] = a[i].x;
+                        if (fcol + 1 < p.N) q[1] = a[i].y;
+                        if (fcol + 2 < p.N) q[2] = a[i].z;
+                    }
+                }
+            }
+        } else {
+            gemm_epilogue_pair<EPI>(p, file, row0 + wave * 32 + 4 * hh, col0 + l31, acc0, acc1);
         }
     } else {
         gemm_epilogue_pair<EPI>(p, file, row0 + wave * 32 + 4 * hh, col0 + l31, acc0, acc1);
     }
-    if constexpr (TAIL && EPI != EPI_DIVFIX) {
+    if (TAIL) {
         if (side_wg) {
-            ring_smem[tid] = tail_acc;
+            s_red[tid] = tail_acc;
             __syncthreads();
             if (tid < BN) {
-                const float s = (ring_smem[tid] + ring_smem[BN + tid]) + (ring_smem[2 * BN + tid] + ring_smem[3 * BN + tid]);
+                const float s = (s_red[tid] + s_red[BN + tid]) + (s_red[2 * BN + tid] + s_red[3 * BN + tid]);
                 const int col = col0 + tid;
                 if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, file, p.tail_row, col, s);
             }

@@ -20,11 +20,6 @@ int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the 
 int gccnmf_tune_ring_depth = 0;    // 0 auto (deep ring when the launch fits one workgroup per CU), else 6 / 10
 int gccnmf_tune_wh_splits = 3;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
 int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
-#define GCCNMF_DEFAULT_H_SPLITS 1
-int gccnmf_tune_h_splits = GCCNMF_DEFAULT_H_SPLITS;      // single-file H update (K2) as a split-K launch with the in-launch combine (EPI_UPDHFIX): parts, 1 = unsplit
-#define GCCNMF_DEFAULT_WH_FIX 0
-int gccnmf_tune_wh_fix = GCCNMF_DEFAULT_WH_FIX;   // single-file split-K of W.H: 0 = partials + nmf_div_partials_kernel, 1 / 2 = the last part to arrive at a
-                                   // tile combines and divides inside the GEMM launch (EPI_DIVFIX, gemm_ring.h; 1 fences, 2 write-through partials)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
@@ -50,14 +45,6 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 7 && (value == 0 || value == 6 || value == 10)) {
         gccnmf_tune_ring_depth = value;
-        return GCCNMF_OK;
-    }
-    if (key == 8 && value >= -1 && value <= 2) {        // -1: back to the default
-        gccnmf_tune_wh_fix = value < 0 ? GCCNMF_DEFAULT_WH_FIX : value;
-        return GCCNMF_OK;
-    }
-    if (key == 9 && (value == -1 || (value >= 1 && value <= 4))) {       // -1: back to the default
-        gccnmf_tune_h_splits = value < 0 ? GCCNMF_DEFAULT_H_SPLITS : value;
         return GCCNMF_OK;
     }
     if ((key == 5 || key == 6) && value >= 1 && value <= 4) {
@@ -458,27 +445,6 @@ static int launch_update_h(const NmfGeom& g, const float* W, long sW, const floa
     return dispatch_gemm<false, false, EPI_UPDH>(a, false, s);
 }
 
-// One file alone: the same update as a split-K launch of the ring kernel -- every part stores its partial W^T.R tile, the last part
-// to arrive at a tile combines them and rewrites H (EPI_UPDHFIX, gemm_ring.h).  P: nsplit x Kp x Np floats.
-static int launch_update_h_split(const NmfGeom& g, const float* W, const float* R, float* H, const float* hscale, const float* colsumW,
-                                 float alpha, float eps, float* P, unsigned* fix_counters, int nsplit, int fix_mode, hipStream_t s) {
-    GemmArgs a = {};
-    a.A = W; a.lda = g.Kp; a.a_clamp = g.Kp - 4;
-    a.B = R; a.ldb = g.Np; a.b_clamp = g.Np - 4;
-    a.M = g.K; a.N = g.N; a.Kd = g.F;
-    if ((g.F % 16) == 1) {
-        a.Kd = g.F - 1;
-        a.ktailA = W + (long)(g.F - 1) * g.Kp;
-        a.ktailB = R + (long)(g.F - 1) * g.Np;
-    }
-    a.batch = nsplit; a.kparts = nsplit; a.xcd_affine = 0;
-    a.C = P; a.sC = g.sH; a.ldc = g.Np;
-    a.C2 = H; a.fix_counter = fix_counters; a.fix_mode = fix_mode;
-    a.E1 = hscale; a.E2 = colsumW;
-    a.alpha = alpha; a.eps = eps;
-    return gccnmf_launch_gemm_ring<false, false, EPI_UPDHFIX, false>(a, s);
-}
-
 // U = R . H^T, rowsumH = sum_n H
 static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U, float* rowsumH, int batch, int xcd,
                       hipStream_t s) {
@@ -555,7 +521,7 @@ static bool single_file_split(const NmfGeom& g, int batch, int reduction, int sp
 
 // P_part = W[:, part] . (hscale * H)[part, :]   (EPI_STORE incl. the VALU tail row), then R = V / sum_part P_part
 static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W, const float* H, const float* hscale, float* P, float* R,
-                               unsigned* fix_counters, hipStream_t s) {
+                               hipStream_t s) {
     const int nsplit = gccnmf_tune_wh_splits;
     const bool ring = gccnmf_tune_ring && gccnmf_ring_supports(g.Kp);
     const int len = g.Kp / nsplit;                           // atoms per part (multiple of 16) -- equal parts for the register-staged kernel
@@ -571,10 +537,6 @@ static int launch_wh_div_split(const NmfGeom& g, const float* V, const float* W,
     }
     a.tail_row = g.F - 1;
     a.C = P; a.sC = g.sV; a.ldc = g.Np;
-    if (ring && gccnmf_tune_wh_fix) {                        // combine + divide inside the launch: no second kernel
-        a.E0 = V; a.C2 = R; a.fix_counter = fix_counters; a.fix_mode = gccnmf_tune_wh_fix;
-        return g.tail ? gccnmf_launch_gemm_ring<true, false, EPI_DIVFIX, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_DIVFIX, false>(a, s);
-    }
     int rc;
     if (ring)
         rc = g.tail ? gccnmf_launch_gemm_ring<true, false, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, false, EPI_STORE, false>(a, s);
@@ -609,28 +571,15 @@ static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, fl
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }
 
-// arrival counters of the in-launch split-K combine: one 32-bit word per 128 x 64 output tile of W.H (rounded up to whole 1 KB)
-static long fix_counter_words(const NmfGeom& g) {
-    const int rows = g.Fm > g.K ? g.Fm : g.K;          // W.H tiles (F x N) or H-update tiles (K x N): the two launches never overlap
-    return 256L * gccnmf_ceil_div(gccnmf_ceil_div(rows, 128) * gccnmf_ceil_div(g.N, 64), 256);
-}
-// H-update split-K (tuning key 9): reduction over F cut in parts of at least 8 k-tiles, one file alone, ring kernel
-static bool single_file_split_h(const NmfGeom& g, int batch) {
-    const int red = (g.F % 16) == 1 ? g.F - 1 : g.F;
-    return batch == 1 && gccnmf_tune_h_splits > 1 && gccnmf_tune_ring && gccnmf_tune_tile_policy != 1 && gccnmf_ring_supports(red) &&
-           red / 16 >= 8 * gccnmf_tune_h_splits;
-}
-
 extern "C" {
 
 // R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
 // GCCNMF_SPLITS x max(Fp*Np, Fp*Kp) (W.H parts and R.H^T parts use the same memory at different stages) + GCCNMF_SPLITS x Kp
-// | arrival counters of the in-launch combines (one word per output tile) | GCCNMF_SPLITS x Kp*Np (parts of the split H update)
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
     long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
-    if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp) + fix_counter_words(g) + GCCNMF_SPLITS * g.sH;
+    if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
     return n;
 }
 
@@ -645,8 +594,6 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* hscale = rowsumH + (long)batch * g.Kp;
     float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
-    unsigned* fix_counters = (unsigned*)(rowsum_parts + GCCNMF_SPLITS * (long)g.Kp);
-    float* h_parts = (float*)(fix_counters + fix_counter_words(g));
     const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
     const int xcd = (flags & 1) ? 0 : 1;
@@ -655,19 +602,14 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
         case 0:
             // R's padding (rows >= F, columns >= N) must be zero: it is a reduction operand of K2 and K4a.
             if (hipMemsetAsync(R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-            if (batch == 1 && hipMemsetAsync(fix_counters, 0, sizeof(unsigned) * fix_counter_words(g), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
             hipLaunchKernelGGL(nmf_prepare_kernel, dim3(vec_grid), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
             break;
         case 1:
-            if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, fix_counters, s);
+            if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
-        case 2:
-            if (single_file_split_h(g, batch))
-                return launch_update_h_split(g, W, R, H, hscale, colsumW, alpha, eps, h_parts, fix_counters, gccnmf_tune_h_splits,
-                                             gccnmf_tune_wh_fix ? gccnmf_tune_wh_fix : 1, s);
-            return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
+        case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
         case 3:
-            if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, fix_counters, s);
+            if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
         case 4:
             if (split_rht) return launch_rht_split(g, R, H, parts, rowsum_parts, s);

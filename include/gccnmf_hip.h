@@ -45,13 +45,7 @@ int gccnmf_version(void);
  * 16 no epilogue.  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
  * 2 always the 128x64 small-batch tile (results stay valid; used by the tests to cover both paths at any size).
  * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
- * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs).
- * key 4: 1 (default) = small launches on the LDS-DMA ring kernel (csrc/gemm_ring.h), 0 = register-staged.  keys 5 / 6: split-K parts
- * of W.H / R.H^T when ONE mixture is processed alone (1..4).  key 7: ring depth (0 auto, 6, 10).  key 8: how the split-K parts of
- * W.H are combined -- 0 = a second launch (nmf_div_partials_kernel), 1 / 2 = inside the GEMM launch by the part that arrives last
- * at a tile (1: agent-scope fences, 2: write-through partial stores; bit-identical results either way), -1 = the default.
- * key 9: split-K parts of the H update (W^T.R) when one mixture is processed alone (1 = unsplit, 2..4; combined inside the launch
- * as for key 8), -1 = the default. */
+ * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs). */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */

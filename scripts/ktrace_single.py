@@ -20,6 +20,9 @@ def main():
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
+    for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE=8=2,9=3
+        key, val = [int(v) for v in kv.split('=')]
+        assert lib.gccnmf_set_tuning(key, val) == 0, kv
     F, T, K, B = 513, 622, a.K, 1
     g = Geometry(F, T, K)
     N = g.N

@@ -40,29 +40,11 @@ def run(label, reps=3):
     return e.y.clone()
 
 
-for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE=8=1,9=3
+for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE=5=2,6=4
     key, val = [int(v) for v in kv.split('=')]
     assert lib.gccnmf_set_tuning(key, val) == 0, kv
 if '--profile' in sys.argv:
     run('default', 2)
-    sys.exit(0)
-if '--fix' in sys.argv:          # how the W.H split-K parts are combined (tuning key 8), for 2 / 3 / 4 parts
-    for wh in (3, 2, 4):
-        lib.gccnmf_set_tuning(5, wh)
-        ys = []
-        for fix in (0, 1, 2):
-            lib.gccnmf_set_tuning(8, fix)
-            ys.append(run('W.H in %d parts, combine %s' % (wh, ('second launch', 'in launch (fences)', 'in launch (write-through)')[fix])))
-        print('    bit-identical waveforms: %s' % (bool(torch.equal(ys[0], ys[1])) and bool(torch.equal(ys[0], ys[2]))), flush=True)
-    lib.gccnmf_set_tuning(5, 3)
-    lib.gccnmf_set_tuning(8, 0)
-    ys = [run('baseline again: W.H in 3 parts, second launch, H update unsplit')]
-    for fix in (0, 1, 2):         # ... and the H update as a split-K launch with the in-launch combine (tuning key 9)
-        lib.gccnmf_set_tuning(8, fix)
-        for hs in (2, 3, 4):
-            lib.gccnmf_set_tuning(9, hs)
-            y = run('W.H combine mode %d, H update in %d parts' % (fix, hs))
-            print('    waveform rms vs unsplit H update: %.2e' % float(((y - ys[0]) ** 2).mean().sqrt()), flush=True)
     sys.exit(0)
 lib.gccnmf_set_tuning(4, 0)
 y_old = run('register-staged (round 1)')

@@ -348,7 +348,11 @@ def test_reference_call_sequence_dropin(hip, scene):
     targetSignalEstimates = getTargetSignalEstimates(targetSpectrogramEstimates, windowSize, hopSize, hanning)
     assert targetTDOAIndexes == r['idx']
     assert rel(W, r['W']) < 1e-4 and rel(H, r['H']) < 1e-4
-    assert np.mean(np.argmax(targetCoefficientMasks, 0) != np.argmax(r['M'], 0)) < 1e-3
+    # the masks are exact except at genuine near-ties of the oracle's own two best target scores
+    flipped = np.argmax(targetCoefficientMasks, 0) != np.argmax(r['M'], 0)
+    srt = np.sort(np.asarray(r['G'], np.float64), axis=0)
+    gap = (srt[-1] - srt[-2]) / np.maximum(np.abs(srt[-1]), 1e-300)
+    assert (gap[flipped] < 1e-4).all(), (int(flipped.sum()), float(gap[flipped].max()))
     assert targetSignalEstimates.shape == r['y'].shape and targetSignalEstimates.dtype == np.float32
     rms = np.sqrt(np.mean((targetSignalEstimates.astype(np.float64) - r['y']) ** 2))
     assert rms < 1e-4, rms

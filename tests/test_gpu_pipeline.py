@@ -361,81 +361,6 @@ def test_klnmf_repeats_are_bitwise_identical():
         assert torch.equal(e1.W, W1)
 
 
-@pytest.mark.parametrize('n,n_fft,K,iters', [(160000, 1024, 1024, 8), (90000, 1024, 640, 6), (70000, 512, 512, 6), (50000, 1024, 520, 5)])
-@pytest.mark.parametrize('mode', [1, 2])
-def test_single_file_in_launch_split_k_combine_is_bitwise_the_two_launch_form(n, n_fft, K, iters, mode):
-    """One mixture alone: W.H is cut into split-K parts.  With tuning key 8 the part that arrives LAST at an output tile adds the
-    partials (ascending part order) and divides inside the GEMM launch (EPI_DIVFIX, csrc/gemm_ring.h) instead of a second
-    combine launch: same values added in the same order, so the factors must be BIT-identical to the two-launch form -- on every
-    repeat (the arrival order changes from launch to launch; the cross-XCD visibility of the partials is what this test watches),
-    for both visibility schemes (1: agent-scope fences, 2: write-through partial stores), with and without the VALU tail row
-    (n_fft 512 -> F = 257 has one too; ragged column tiles in every case) and with unequal parts."""
-    from gcc_nmf_amd import _hip
-    lib = _hip.lib()
-    x = O.synthetic_mixture(11, numSamples=n)
-    e = engine(n, windowSize=n_fft, hopSize=n_fft // 4, dictionarySize=K, numIterations=iters, batch=1)
-    e.upload(x)
-    e.stft()
-    try:
-        assert lib.gccnmf_set_tuning(8, 0) == 0
-        e.klnmf()
-        W0, H0 = e.W.clone(), e.H.clone()
-        assert torch.isfinite(W0).all() and torch.isfinite(H0).all()
-        assert lib.gccnmf_set_tuning(8, mode) == 0
-        for _ in range(10):
-            e.klnmf()
-            assert torch.equal(e.W, W0) and torch.equal(e.H, H0)
-        for splits in (2, 4):                      # other part counts (default 3)
-            assert lib.gccnmf_set_tuning(5, splits) == 0 and lib.gccnmf_set_tuning(8, 0) == 0
-            e.klnmf()
-            Ws, Hs = e.W.clone(), e.H.clone()
-            assert lib.gccnmf_set_tuning(8, mode) == 0
-            for _ in range(3):
-                e.klnmf()
-                assert torch.equal(e.W, Ws) and torch.equal(e.H, Hs)
-    finally:
-        lib.gccnmf_set_tuning(5, 3)
-        lib.gccnmf_set_tuning(8, -1)                # the library's default
-
-
-@pytest.mark.parametrize('n,n_fft,K,iters', [(160000, 1024, 1024, 8), (90000, 1024, 640, 6), (70000, 512, 512, 6)])
-def test_single_file_split_k_h_update(n, n_fft, K, iters):
-    """One mixture alone, tuning key 9: the H update (W^T.R, reduction over F) as a split-K launch whose last-arriving part combines the
-    partial tiles and rewrites H in place (EPI_UPDHFIX).  Deterministic (bit-identical repeats, both visibility schemes give the same
-    bits), within summation-order distance of the unsplit launch, and within the usual 1e-4 of the oracle."""
-    from gcc_nmf_amd import _hip
-    lib = _hip.lib()
-    x = O.synthetic_mixture(12, numSamples=n)
-    e = engine(n, windowSize=n_fft, hopSize=n_fft // 4, dictionarySize=K, numIterations=iters, batch=1)
-    e.upload(x)
-    e.stft()
-    try:
-        assert lib.gccnmf_set_tuning(9, 1) == 0
-        e.klnmf()
-        W0, H0 = e.W.clone(), e.H.clone()
-        for parts in (3, 2):
-            assert lib.gccnmf_set_tuning(9, parts) == 0
-            first = None
-            for mode in (1, 2):
-                assert lib.gccnmf_set_tuning(8, mode) == 0
-                for _ in range(5):
-                    e.klnmf()
-                    if first is None:
-                        first = (e.W.clone(), e.H.clone())
-                        assert torch.isfinite(first[0]).all() and torch.isfinite(first[1]).all()
-                    assert torch.equal(e.W, first[0]) and torch.equal(e.H, first[1])
-            dW = float((first[0] - W0).norm() / W0.norm())
-            dH = float((first[1] - H0).norm() / H0.norm())
-            assert 0 < dW < 1e-5 and 0 < dH < 1e-5, (dW, dH)            # another summation order, nothing more
-        W, H = e.get_WH()
-        V = e.get_V()[0]
-        Wr, Hr = O.performKLNMF(V, K, iters, 0)
-        assert rel(W[0], Wr) < 1e-4 and rel(H[0], Hr) < 1e-4
-    finally:
-        lib.gccnmf_set_tuning(9, -1)
-        lib.gccnmf_set_tuning(8, -1)
-
-
 def test_pcm16_egress_reports_non_finite_waveforms():
     """A NaN / Inf in a separated waveform must not become arbitrary PCM silently: the peak image flags it."""
     n = 20000

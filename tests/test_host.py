@@ -41,7 +41,7 @@ def test_pitches_and_workspace_sizes():
     assert lib.gccnmf_pitches(1, 622, 128, *[ctypes.byref(x) for x in v]) == 1           # GCCNMF_ERR_ARG
     base = 528 * 1280 + 528 * 1024 + 3 * 1024                      # R, U, three K-vectors per file
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * base
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + 256 + 4 * 1024 * 1280   # one file alone: + split-K partials, arrival counters (whole KB), H-update parts
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024)      # + the split-K partials of one file alone
     assert lib.gccnmf_klnmf_workspace_floats(513, 0, 1024, 1) == -1
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.gccnmf_klnmf(0, 0, 0, 0, 513, 1244, 1024, 1, 1, 0.0, 1e-16, 0, 0) == 1
