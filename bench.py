@@ -370,12 +370,11 @@ def main():
 
     if rank == 0:
         # host float32 samples in -> host float32 waveforms out (PCIe both ways); reported beside `value`, never as `value`
+        e.separate(xs)                                           # allocates the page-locked staging buffers (slow, once per engine)
         t1 = time.perf_counter()
         e.separate(xs)
         out['host_to_host_frames_per_s'] = B * g.T / (time.perf_counter() - t1)           # one batch, copies not overlapped
         nb = 8                                                   # fill + drain of the pipeline are ~1/3 of a batch time: amortised over 8
-        for _y in e.separate_batches(xs for _ in range(2)):      # allocates the pinned staging buffers
-            pass
         t1 = time.perf_counter()
         for _y in e.separate_batches(xs for _ in range(nb)):
             pass
@@ -443,10 +442,17 @@ def main():
         out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
                                'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle '
                                          '(oracle/gccnmf_oracle.py; its angular-spectrum and score contractions are GEMM restatements, '
-                                         'so it is FASTER than the reference code), %.1f s.  The unmodified reference functions on the '
-                                         'same file and parameters: 68.5 frames/s end to end on the 8 cores of the build container '
-                                         '(SURVEY section 6; it cannot travel to the GPU box)' % (B, g.T, dt),
+                                         'so it is FASTER than the reference code), %.1f s.  The reference checkout cannot travel with the '
+                                         'repository; `reference_on_gpu_box` is the kept record of its unmodified functions timed on a GPU '
+                                         "box's host cores (scripts/time_reference_cpu.py, checkout staged for that one call)" % (B, g.T, dt),
                                'host_cpus': os.cpu_count()}
+        rec = os.path.join(REPO, 'profiles', 'reference_cpu_on_gpu_box.json')
+        if os.path.exists(rec) and K == 1024 and iters == 100 and a.hop == 256 and a.seconds == 10.0:
+            r0 = json.load(open(rec))
+            out['cpu_baseline']['reference_on_gpu_box'] = {
+                'frames_per_s': r0['frames_per_s'], 'nmf_only_frames_per_s': r0['nmf_only_frames_per_s'], 'host_cpus': r0['host_cpus'],
+                'blas_threads': max(t['num_threads'] for t in r0['thread_pools']) if r0.get('thread_pools') else None,
+                'source': 'profiles/reference_cpu_on_gpu_box.json (same file 0, same parameters; recorded once, not re-timed here)'}
         y0 = e.y[0].cpu().numpy()
         out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))
         out['gpu_vs_cpu_tdoa_equal'] = bool(e.get_tdoa_indexes()[0].tolist() == r['idx'])

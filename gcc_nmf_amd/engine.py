@@ -153,6 +153,11 @@ class GCCNMFEngine(object):
             # nmf_groups equal group workspaces (for one group == the whole-batch workspace)
             self.ws_nmf = z(self.nmf_groups * self.lib.gccnmf_klnmf_workspace_floats(F, g.N, g.K, B // self.nmf_groups))
             self.nmf_streams = [torch.cuda.Stream(device=dev) for _ in range(self.nmf_groups)] if self.nmf_groups > 1 else []
+            # Copy streams of separate_batches, created ONCE and right behind the group streams.  The runtime maps streams onto a
+            # few hardware queues in creation order (4 by default), and a queue is in-order: a 244 MB download that shares its queue
+            # with a KL-NMF group holds that group's next kernels back for its 5 ms.  Fresh streams per call walked through torch's
+            # pool and landed on the groups' queues every other call (measured: 264 ms per batch instead of 258).
+            self.copy_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
             self.ang = z(B, g.Dp, g.Tp)
             self.mean_ang = torch.zeros((B, g.Dp), dtype=torch.float64, device=dev)
             self.tdoa_idx = torch.zeros((B, g.S), dtype=torch.int32, device=dev)
@@ -255,9 +260,10 @@ class GCCNMFEngine(object):
                    'gccnmf_istft_ola')
 
     @_on_device
-    def run(self):
+    def run(self, stft=True):
         """samples already in ``self.x`` -> separated waveforms in ``self.y`` (all on device, asynchronous)."""
-        self.stft()
+        if stft:
+            self.stft()
         self.klnmf()
         self.localize()
         self.masks()
@@ -304,11 +310,16 @@ class GCCNMFEngine(object):
     @_on_device
     def separate(self, stereoSamples):
         """(batch, 2, n) float32 host samples -> (batch, S, 2, hop*(T-1)) float32 host waveforms."""
-        self.upload(stereoSamples)
-        self.run()
-        y = self.y.cpu().numpy()
-        self.check_status()
-        return y
+        x = np.asarray(stereoSamples, dtype=np.float32)
+        if x.ndim == 2:
+            x = x[None]
+        # through the page-locked staging buffers of separate_batches (allocated on first use): 82 MB up and 244 MB down per 64-file
+        # batch move at PCIe speed instead of through pageable bounce buffers (313 -> 285 ms host to host for one batch)
+        batches = self.separate_batches([x])
+        try:
+            return next(batches)
+        finally:
+            batches.close()
 
     def separate_batches(self, batches):
         """Generator over an iterable of (batch, 2, n) float32 host arrays -> one (batch, S, 2, hop*(T-1)) float32 array per
@@ -319,7 +330,7 @@ class GCCNMFEngine(object):
         g = self.g
         with torch.cuda.device(dev):
             compute = torch.cuda.current_stream(dev)
-            s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            s_in, s_out = self.copy_streams
             if getattr(self, '_pipe', None) is None:       # second device buffers + pinned staging: allocated once (page-locking is slow)
                 self._pipe = dict(x=torch.zeros_like(self.x), y=torch.zeros_like(self.y),
                                   hx=[torch.zeros(self.x.shape, dtype=torch.float32).pin_memory() for _ in range(2)],
@@ -331,7 +342,9 @@ class GCCNMFEngine(object):
             ev_in = [torch.cuda.Event() for _ in range(2)]
             ev_done = [torch.cuda.Event() for _ in range(2)]
             ev_out = [torch.cuda.Event() for _ in range(2)]
+            ev_stft = torch.cuda.Event()
             pending = []                       # slots whose results have not been yielded yet, oldest first
+            download = None                    # the deferred download of the batch enqueued last
 
             def collect(slot):
                 ev_out[slot].synchronize()
@@ -358,15 +371,28 @@ class GCCNMFEngine(object):
                     compute.wait_event(ev_in[slot])
                     compute.wait_event(ev_out[slot])                     # batch i-2's waveforms have left this y buffer
                     self.x, self.y, self.pcm_in = xs[slot], ys[slot], None
-                    self.run()
+                    self.stft()
+                    if download is not None:                             # batch i-1 goes down now that this batch's STFT is past
+                        ev_stft.record(compute)
+                        download(ev_stft)
+                    self.run(stft=False)
                     self._pipe['ds'][slot].copy_(self.status)            # per-slot snapshot ON the compute stream: batch i+1's
                     ev_done[slot].record(compute)                        # localize() rewrites self.status before s_out has copied it
-                    with torch.cuda.stream(s_out):
-                        s_out.wait_event(ev_done[slot])
-                        hy[slot].copy_(ys[slot], non_blocking=True)
-                        status[slot].copy_(self._pipe['ds'][slot], non_blocking=True)
-                        ev_out[slot].record(s_out)
+
+                    # The download is a shader copy on this runtime (rocprofv3: __amd_rocclr_copyBuffer, 4.6 ms for 244 MB at PCIe
+                    # speed); next to the HBM-bound STFT of the following batch it held that kernel up from 0.6 to 4.9 ms.  So it is
+                    # enqueued behind that STFT (or at once for the last batch) and runs in the shadow of the MFMA-bound KL-NMF.
+                    def download(after=None, slot=slot):
+                        with torch.cuda.stream(s_out):
+                            s_out.wait_event(ev_done[slot])
+                            if after is not None:
+                                s_out.wait_event(after)
+                            hy[slot].copy_(ys[slot], non_blocking=True)
+                            status[slot].copy_(self._pipe['ds'][slot], non_blocking=True)
+                            ev_out[slot].record(s_out)
                     pending.append(slot)
+                if download is not None:
+                    download()
                 while pending:
                     yield collect(pending.pop(0))
             finally:
