@@ -28,6 +28,9 @@ for mode in shared-dictionary streaming; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_single -o single -- python scripts/single_file.py --profile > $OUT/prof_single.log 2>&1
 grep default $OUT/prof_single.log
+if [ -d oracle/_ref/reference_checkout ]; then     # staged for this one call (scripts/stage_reference.sh): the unmodified reference on this box's host cores
+  timeout 300 python scripts/time_reference_cpu.py > $OUT/reference_cpu.json 2> $OUT/reference_cpu.err; echo "reference exit $?"; cut -c1-400 $OUT/reference_cpu.json
+fi
 find $OUT -name "*kernel_trace*.csv" -size +8M -delete
 if [ -z "$SKIP_PMC" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
