@@ -131,10 +131,13 @@ def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_see
             'config': {'workload': '%d files/GPU, one shared dictionary, all-reduce of %d floats per iteration' %
                                    (B, local.partial.numel()), 'files_per_gpu': B, 'dictionary_size': K, 'nmf_iterations': iters,
                        'parallelism': 'columns sharded x%d, W replicated, 1 all-reduce/iteration' % world},
-            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None,
+            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None, 'collective': local.collective,
+            'iteration_loop': 'gccnmf_klnmf_shared_run: kernels and the all-reduce enqueued from C, one library call per training',
             'dictionary_finite_unit_norm': bool(np.isfinite(W).all() and np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-4)),
         }))
     if world > 1:
+        from gcc_nmf_amd.distributed import destroy_rccl_communicators
+        destroy_rccl_communicators()
         dist.destroy_process_group()
 
 
@@ -174,14 +177,17 @@ def time_sharded_mode(a, world, rank, local_rank, barrier, ranks_seen, backend):
             'value': local.T_total * a.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'one %.0f s stereo mixture (%d frames), host samples in -> host waveform segments out; frames sharded x%d, '
+            'config': {'workload': 'one %.0f s stereo mixture (%d frames), samples resident in HBM -> host waveform segments out; frames sharded x%d, '
                                    'W replicated: %d all-reduces of F*K+K floats, 1 of 128 doubles, 1 all-gather of 3 halo frames per signal'
                                    % (seconds, local.T_total, world, a.iterations), 'frames': local.T_total, 'dictionary_size': a.dictionary_size,
                        'nmf_iterations': a.iterations, 'parallelism': 'frame windows sharded x%d' % world},
-            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None,
+            'ranks_seen': ranks_seen, 'collective_backend': backend if world > 1 else None, 'collective': local.nmf.collective,
+            'column_blocks': [list(b) for b in local.nmf.blocks],
             'tdoa_indexes': local.tdoa_indexes().tolist(), 'segment_finite': bool(np.isfinite(seg).all())}))
     if world > 1:
         barrier()
+        from gcc_nmf_amd.distributed import destroy_rccl_communicators
+        destroy_rccl_communicators()
         dist.destroy_process_group()
 
 
@@ -379,6 +385,14 @@ def main():
         for _y in e.separate_batches(xs for _ in range(nb)):
             pass
         out['host_to_host_pipelined_frames_per_s'] = nb * B * g.T / (time.perf_counter() - t1)   # transfers under the neighbours' compute
+        # SURVEY 8(d) defines the metric host float32 samples in -> host float32 waveforms out; the bench contract defines `value`
+        # with the inputs already resident in HBM (and forbids the PCIe-inclusive rate there).  Both are in this line:
+        out['sec8d_host_to_host'] = {'value': out['host_to_host_pipelined_frames_per_s'], 'unit': 'frames/s', 'batches': nb,
+                                     'what': 'SURVEY 8(d) metric: host float32 samples in -> host float32 separated waveforms out, %d batches '
+                                             'of %d files back to back through GCCNMFEngine.separate_batches (pinned staging, copies of batch '
+                                             'i+-1 under the compute of batch i), pipeline fill and drain included' % (nb, B),
+                                     'single_batch_unpipelined': out['host_to_host_frames_per_s'],
+                                     'hbm_resident': frames / elapsed / world}
         traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
 
@@ -431,21 +445,29 @@ def main():
 
     if rank == 0 and world == 1 and not a.skip_cpu_baseline:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline
-        try:
-            from threadpoolctl import threadpool_info
-            threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
-        except Exception:
-            threads = os.cpu_count()
-        t1 = time.perf_counter()
-        r = O.runGCCNMF(xs[0], sr, 1024, a.hop, 128, 1.0, 3, dictionarySize=K, numIterations=iters, return_intermediates=True)
-        dt = time.perf_counter() - t1
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+
+        def oracle_run():
+            t1 = time.perf_counter()
+            r = O.runGCCNMF(xs[0], sr, 1024, a.hop, 128, 1.0, 3, dictionarySize=K, numIterations=iters, return_intermediates=True)
+            return time.perf_counter() - t1, r
+        # best of 3 after one warm-up, all host cores; plus one BLAS thread (OPENBLAS_NUM_THREADS=1 equivalent)
+        oracle_run()
+        runs = [oracle_run() for _ in range(3)]
+        dt, r = min(runs, key=lambda v: v[0])
+        with threadpool_limits(limits=1):
+            dt1, _ = oracle_run()
         out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
-                               'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle '
+                               'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle PORT of the reference '
                                          '(oracle/gccnmf_oracle.py; its angular-spectrum and score contractions are GEMM restatements, '
-                                         'so it is FASTER than the reference code), %.1f s.  The reference checkout cannot travel with the '
-                                         'repository; `reference_on_gpu_box` is the kept record of its unmodified functions timed on a GPU '
-                                         "box's host cores (scripts/time_reference_cpu.py, checkout staged for that one call)" % (B, g.T, dt),
-                               'host_cpus': os.cpu_count()}
+                                         'so it is FASTER than the reference code): best of 3 after one warm-up, %.1f s each.  The reference '
+                                         'checkout cannot travel with the repository; `reference_on_gpu_box` is the kept record of its '
+                                         "unmodified functions timed on a GPU box's host cores (scripts/time_reference_cpu.py, checkout "
+                                         'staged for that one call)' % (B, g.T, dt),
+                               'runs_s': [v[0] for v in runs], 'host_cpus': os.cpu_count(),
+                               'single_thread': {'value': g.T / dt1, 'unit': 'frames/s', 'cores': 1, 'seconds': dt1,
+                                                 'how': 'threadpoolctl.threadpool_limits(1) around the same call (one BLAS thread)'}}
         rec = os.path.join(REPO, 'profiles', 'reference_cpu_on_gpu_box.json')
         if os.path.exists(rec) and K == 1024 and iters == 100 and a.hop == 256 and a.seconds == 10.0:
             r0 = json.load(open(rec))

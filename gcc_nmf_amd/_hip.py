@@ -13,8 +13,18 @@ LIB_PATH = os.environ.get('GCCNMF_HIP_LIB') or os.path.join(_HERE, 'libgccnmf_hi
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 P_INT = ctypes.POINTER(ctypes.c_int)
 
+
+class SharedShard(ctypes.Structure):
+    """gccnmf_shared_shard (include/gccnmf_hip.h)"""
+    _fields_ = [('V', c_void_p), ('H', c_void_p), ('workspace', c_void_p), ('N', c_int), ('batch', c_int), ('ld', c_int)]
+
+
+# gccnmf_allreduce_fn: int (*)(void* ctx, float* buf, long count, void* stream)
+RCCL_UNIQUE_ID_BYTES = 128
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
+
 STATUS = {0: 'GCCNMF_OK', 1: 'GCCNMF_ERR_ARG (bad argument)', 2: 'GCCNMF_ERR_LAUNCH (HIP launch failed)',
-          3: 'GCCNMF_ERR_UNSUPPORTED'}
+          3: 'GCCNMF_ERR_UNSUPPORTED', 4: 'GCCNMF_ERR_COLLECTIVE (all-reduce hook / RCCL failed)'}
 
 # name -> (restype, argtypes); mirrors include/gccnmf_hip.h declaration by declaration
 SIGNATURES = {
@@ -38,6 +48,15 @@ SIGNATURES = {
                                            c_int, c_float, c_float, c_void_p]),
     'gccnmf_klnmf_shared_step_b': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'gccnmf_klnmf_shared_finish': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'gccnmf_klnmf_shared_shard_workspace_floats': (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    'gccnmf_klnmf_shared_run': (c_int, [ctypes.POINTER(SharedShard), c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                        c_float, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_rccl_available': (c_int, []),
+    'gccnmf_rccl_unique_id': (c_int, [ctypes.c_char_p]),
+    'gccnmf_rccl_comm_init': (c_int, [ctypes.c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'gccnmf_rccl_comm_destroy': (c_int, [c_void_p]),
+    'gccnmf_rccl_allreduce': (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    'gccnmf_rccl_allreduce_hook': (c_void_p, []),
     'gccnmf_angular_spectrogram': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p]),
     'gccnmf_pick_tdoa_peaks': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -243,8 +243,13 @@ struct GemmEpiloguePair {
                     ub[r] = fmaf(tav[i], bb, ub[r]);
                 }
                 if (EPI == EPI_DIV) {
-                    ua[r] = gemm_div_fast(xa[r], ua[r]);
-                    ub[r] = gemm_div_fast(xb[r], ub[r]);
+                    if (p.exact_div) {          // tuning key 7: the IEEE quotient, as the reference's numpy.divide (wave-uniform branch)
+                        ua[r] = xa[r] / ua[r];
+                        ub[r] = xb[r] / ub[r];
+                    } else {
+                        ua[r] = gemm_div_fast(xa[r], ua[r]);
+                        ub[r] = gemm_div_fast(xb[r], ub[r]);
+                    }
                 } else if (EPI == EPI_UPDH) {
                     ua[r] = (xa[r] * ua[r]) * gv[i];
                     ub[r] = (xb[r] * ub[r]) * gv[i];
@@ -806,6 +811,7 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
     if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
     a.ablate = gccnmf_tune_ablate;
+    a.exact_div = gccnmf_tune_exact_div;
     a.tiles_m = gccnmf_ceil_div(a.M, 512);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     const int tiles = a.tiles_m * a.tiles_n;

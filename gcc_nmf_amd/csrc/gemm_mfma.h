@@ -41,6 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // run-time tuning knobs (gccnmf_set_tuning); defined in nmf.hip
 extern int gccnmf_tune_ablate;
+extern int gccnmf_tune_exact_div;
 extern long long* gccnmf_trace_buf;
 extern int gccnmf_trace_blocks;
 
@@ -61,6 +62,7 @@ struct GemmArgs {
     int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
     int tiles_m, tiles_n, batch, xcd_affine;
     int kparts;                // ring kernel only: > 0 = the `batch` "files" are kparts balanced parts of ONE reduction of Kd (split-K, partial outputs sC apart)
+    int exact_div;             // LDS-DMA kernel, EPI_DIV: 1 = IEEE division instead of v_rcp_f32 + one Newton step (tuning key 7)
     int ablate;                // timing experiments: 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row, 16 no epilogue (results invalid)
     const float* bscale;       // optional per-reduction-index scale applied to B while staging (non-KC B only)
     long s_bscale;

@@ -21,6 +21,8 @@
 // alternate k-tiles (two waves per SIMD: same time per k-tile), and padding the reduction-strided LDS images against the 2-way
 // bank conflict between the two lane halves of a fragment read (same).
 #pragma once
+#include <atomic>
+#define GCCNMF_MAX_DEVICES 64
 #include <type_traits>
 #include "gemm_dma.h"
 
@@ -448,12 +450,16 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_ring_kernel(GemmArgs p) {
 // loop is not latency-bound -- measured with 10 stages.)
 template <bool A_KC, bool B_KC, int EPI, bool TAIL, int NSTAGE>
 static int gccnmf_launch_gemm_ring_n(const GemmArgs& a, size_t lds, hipStream_t stream) {
-    static size_t configured = 0;      // per instantiation
-    if (lds > configured) {
+    // the attribute is per device AND per instantiation; the cache is keyed by the current device (several engines on several devices
+    // may share this process) and atomic (a stale read only repeats the call)
+    static std::atomic<size_t> configured[GCCNMF_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    if (dev < 0 || dev >= GCCNMF_MAX_DEVICES || lds > configured[dev].load(std::memory_order_relaxed)) {
         if (hipFuncSetAttribute((const void*)gccnmf_gemm_ring_kernel<A_KC, B_KC, EPI, TAIL, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return GCCNMF_ERR_LAUNCH;
-        configured = lds;
+        if (dev >= 0 && dev < GCCNMF_MAX_DEVICES) configured[dev].store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((gccnmf_gemm_ring_kernel<A_KC, B_KC, EPI, TAIL, NSTAGE>), dim3(a.batch * a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
     GCCNMF_CHECK_LAUNCH();

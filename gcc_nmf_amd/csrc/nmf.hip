@@ -10,14 +10,14 @@
 // The compensating rescale H *= norms (:81) is NOT a separate pass over H: it is the vector s,
 // applied while K1 stages its B operand and inside K2's epilogue (which rewrites H anyway).
 // gccnmf_klnmf materialises it once after the last iteration.
-extern int gccnmf_tune_ring_depth;
 #include "gemm_ring.h"
+#include "../../include/gccnmf_hip.h"
 
 int gccnmf_tune_ablate = 0;
+int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
-int gccnmf_tune_ring_depth = 0;    // 0 auto (deep ring when the launch fits one workgroup per CU), else 6 / 10
 int gccnmf_tune_wh_splits = 3;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
 int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
 long long* gccnmf_trace_buf = nullptr;
@@ -43,8 +43,8 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_ring = value ? 1 : 0;
         return GCCNMF_OK;
     }
-    if (key == 7 && (value == 0 || value == 6 || value == 10)) {
-        gccnmf_tune_ring_depth = value;
+    if (key == 7 && (value == 0 || value == 1)) {
+        gccnmf_tune_exact_div = value;
         return GCCNMF_OK;
     }
     if ((key == 5 || key == 6) && value >= 1 && value <= 4) {
@@ -317,12 +317,13 @@ static int launch_update_w(float* W, const float* U, const float* rowsumH, float
     return GCCNMF_OK;
 }
 
-// H[k][:] *= hscale[k].  grid = batch * K rows, 256 threads.  (sScale = 0: one shared scale vector)
+// H[k][:] *= hscale[k].  grid = batch * K rows, 256 threads.  (sScale = 0: one shared scale vector; file b starts sH floats after
+// file b-1, rows are ld floats apart, Np of them are touched)
 __global__ __launch_bounds__(256) void nmf_scale_h_kernel(float* __restrict__ H, const float* __restrict__ hscale, long sScale,
-                                                          int K, int Kp, int Np) {
+                                                          int K, long sH, int ld, int Np) {
     const int b = blockIdx.x / K, k = blockIdx.x - b * K;
     const float s = hscale[b * sScale + k];
-    float4* row = (float4*)(H + ((long)b * Kp + k) * Np);
+    float4* row = (float4*)(H + b * sH + (long)k * ld);
     for (int i = threadIdx.x; i < Np / 4; i += 256) {
         float4 v = row[i];
         v.x *= s;
@@ -338,14 +339,15 @@ __global__ __launch_bounds__(256) void nmf_fill_kernel(float* __restrict__ p, fl
     if (i < n) p[i] = v;
 }
 
-// out[i] = sum_b in[b*stride + i], files added in ascending order (deterministic).
+// out[i] = sum_b in[b*stride + i], files added in ascending order (deterministic); accumulate: out[i] += that sum (a rank's
+// second, third ... shard: the shards' sums are added in shard order).
 __global__ __launch_bounds__(256) void nmf_reduce_files_kernel(const float* __restrict__ in, long stride, int batch, long n,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, int accumulate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int b = 0; b < batch; ++b) s += in[b * stride + i];
-    out[i] = s;
+    out[i] = accumulate ? out[i] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,6 +392,7 @@ static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
 
 struct NmfGeom {
     int F, N, K, Fp, Kp, Np;
+    int ld;         // row pitch (floats) of V, R and H: Np for back-to-back files, the big matrix's pitch for column blocks
     int Fm;         // rows computed on the matrix cores
     bool tail;      // F % 128 == 1: the last bin rides on the VALU
     long sV, sW, sH, sU;
@@ -400,6 +403,7 @@ static NmfGeom make_geom(int F, int N, int K) {
     GccNmfPitches p = gccnmf_make_pitches(F, 1, K);
     g.F = F; g.N = N; g.K = K;
     g.Fp = p.Fp; g.Kp = p.Kp; g.Np = gccnmf_round_up(N, 64);
+    g.ld = g.Np;
     g.tail = (F % 128) == 1 && F > 1;
     g.Fm = g.tail ? F - 1 : F;
     g.sV = (long)g.Fp * g.Np;
@@ -414,12 +418,12 @@ static int launch_wh_div(const NmfGeom& g, const float* V, const float* W, long 
                          long sScale, float* R, int batch, int xcd, hipStream_t s) {
     GemmArgs a = {};
     a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
-    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Np - 4;
+    a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Np - 4;
     a.M = g.Fm; a.N = g.N; a.Kd = g.K;
     a.batch = batch; a.xcd_affine = xcd;
     a.bscale = hscale; a.s_bscale = sScale;
     a.tail_row = g.F - 1;
-    a.C = R; a.sC = g.sV; a.ldc = g.Np;
+    a.C = R; a.sC = g.sV; a.ldc = g.ld;
     a.E0 = V; a.sE0 = g.sV;
     return dispatch_gemm<true, false, EPI_DIV>(a, g.tail, s);
 }
@@ -430,15 +434,15 @@ static int launch_update_h(const NmfGeom& g, const float* W, long sW, const floa
                            hipStream_t s) {
     GemmArgs a = {};
     a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Kp - 4;
-    a.B = R; a.sB = g.sV; a.ldb = g.Np; a.b_clamp = g.Np - 4;
+    a.B = R; a.sB = g.sV; a.ldb = g.ld; a.b_clamp = g.Np - 4;
     a.M = g.K; a.N = g.N; a.Kd = g.F;
     if ((g.F % 16) == 1) {   // F = 16*n + 1: bin F-1 leaves the matrix cores and becomes a rank-1 term of the epilogue
         a.Kd = g.F - 1;
         a.ktailA = W + (long)(g.F - 1) * g.Kp; a.s_ktailA = sW;
-        a.ktailB = R + (long)(g.F - 1) * g.Np; a.s_ktailB = g.sV;
+        a.ktailB = R + (long)(g.F - 1) * g.ld; a.s_ktailB = g.sV;
     }
     a.batch = batch; a.xcd_affine = xcd;
-    a.C = H; a.sC = g.sH; a.ldc = g.Np;
+    a.C = H; a.sC = g.sH; a.ldc = g.ld;
     a.E1 = hscale; a.sE1 = sScale;
     a.E2 = colsumW; a.sE2 = sVec;
     a.alpha = alpha; a.eps = eps;
@@ -449,8 +453,8 @@ static int launch_update_h(const NmfGeom& g, const float* W, long sW, const floa
 static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U, float* rowsumH, int batch, int xcd,
                       hipStream_t s) {
     GemmArgs a = {};
-    a.A = R; a.sA = g.sV; a.lda = g.Np; a.a_clamp = g.Fp - 1;
-    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
+    a.A = R; a.sA = g.sV; a.lda = g.ld; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = g.N;
     a.batch = batch; a.xcd_affine = xcd;
     a.tail_row = g.F - 1;
@@ -469,8 +473,8 @@ static bool can_fuse_w_update(const NmfGeom& g, int batch) {
 static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H, float* W, float* colsumW, float* hscale, int batch,
                                int xcd, hipStream_t s) {
     GemmArgs a = {};
-    a.A = R; a.sA = g.sV; a.lda = g.Np; a.a_clamp = g.Fp - 1;
-    a.B = H; a.sB = g.sH; a.ldb = g.Np; a.b_clamp = g.Kp - 1;
+    a.A = R; a.sA = g.sV; a.lda = g.ld; a.a_clamp = g.Fp - 1;
+    a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = g.N;
     a.batch = batch; a.xcd_affine = xcd;
     a.tail_row = g.F - 1;
@@ -622,7 +626,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return GCCNMF_OK;     // done by stage 4's epilogue
             return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s);
         case 6:
-            hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.Kp, g.Np);
+            hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.sH, g.ld, g.Np);
             break;
         default: return GCCNMF_ERR_ARG;
     }
@@ -650,24 +654,102 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
 }
 
 // ---- shared dictionary (one W for every file / rank) ------------------------------------------
-// workspace: R [batch][Fp][Np] | Upart [batch][Fp][Kp] | rowsum_part [batch][Kp] | colsumW [Kp] | hscale [Kp]
-struct SharedWs {
-    float *R, *Upart, *rowsum_part, *colsumW, *hscale;
+// A rank's columns come as SHARDS: `batch` files of N columns each, either whole padded matrices back to back
+// ([batch][Fp][Np] / [batch][Kp][Np], ld = 0) or -- ld > 0 -- column blocks of ONE matrix with row pitch ld (file b = columns
+// [b*N, b*N+N) of V [Fp][ld], H [Kp][ld]; N a multiple of 64 unless batch == 1): the frame windows of one long mixture need no
+// gather / scatter that way.  Per shard scratch: R (same layout as V) | Upart [batch][Fp][Kp] | rowsum_part [batch][Kp].
+// Shared by all shards of a rank: W, vec = colsumW [Kp] | hscale [Kp], partial = num [Fp][Kp] | den [Kp].
+struct SharedShard {
+    const float* V;
+    float *H, *R, *Upart, *rowsum_part;
+    NmfGeom g;
+    int batch;
+    long r_floats;
 };
-static SharedWs carve_shared(float* ws, const NmfGeom& g, int batch) {
-    SharedWs w;
-    w.R = ws;
-    w.Upart = w.R + (long)batch * g.sV;
-    w.rowsum_part = w.Upart + (long)batch * g.sU;
-    w.colsumW = w.rowsum_part + (long)batch * g.Kp;
-    w.hscale = w.colsumW + g.Kp;
-    return w;
+
+static long shared_r_floats(const NmfGeom& g, int batch, int ld) { return ld > 0 ? (long)g.Fp * ld : (long)batch * g.sV; }
+
+static bool shared_shard_ok(int F, int N, int K, int batch, int ld) {
+    if (F < 2 || N < 1 || K < 1 || batch < 1 || ld < 0) return false;
+    if (ld > 0 && ((ld & 3) || (long)batch * N > ld || (batch > 1 && (N & 63)))) return false;
+    return true;
 }
 
+static SharedShard make_shard(const float* V, float* H, float* ws, int F, int N, int K, int batch, int ld) {
+    SharedShard sh;
+    sh.g = make_geom(F, N, K);
+    if (ld > 0) {
+        sh.g.ld = ld;
+        sh.g.sV = sh.g.sH = N;              // the next file is the next column block
+    }
+    sh.V = V; sh.H = H; sh.batch = batch;
+    sh.r_floats = shared_r_floats(sh.g, batch, ld);
+    sh.R = ws;
+    sh.Upart = sh.R + sh.r_floats;
+    sh.rowsum_part = sh.Upart + (long)batch * sh.g.sU;
+    return sh;
+}
+
+static int shared_begin(const SharedShard* sh, int n, const float* W, float* colsumW, float* hscale, int F, int K, hipStream_t s) {
+    NmfGeom g = make_geom(F, 1, K);
+    for (int i = 0; i < n; ++i)      // R's padding (rows >= F, columns >= N) is a reduction operand of K2 and K4a: zero
+        if (hipMemsetAsync(sh[i].R, 0, sizeof(float) * sh[i].r_floats, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 16), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// H update with the current W, then partial (+)= [sum_files (V/WH).H^T || sum_files rowsum H]
+static int shared_step_a(const SharedShard& sh, const float* W, const float* colsumW, const float* hscale, float* partial,
+                         int accumulate, float alpha, float eps, hipStream_t s) {
+    const NmfGeom& g = sh.g;
+    int rc;
+    // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
+    // through that XCD's L2), exactly as the per-file-dictionary path does
+    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, hscale, 0, sh.R, sh.batch, 1, s))) return rc;
+    if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, sh.batch, 1, s))) return rc;
+    // (H now carries the previous normalisation; K3 below takes no scale, and step B rewrites hscale before anyone reads it again)
+    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, nullptr, 0, sh.R, sh.batch, 1, s))) return rc;
+    if ((rc = launch_rht(g, sh.R, sh.H, sh.Upart, sh.rowsum_part, sh.batch, 1, s))) return rc;
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)((g.sU + 255) / 256)), dim3(256), 0, s, sh.Upart, g.sU, sh.batch, g.sU,
+                       partial, accumulate);
+    GCCNMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, sh.rowsum_part, (long)g.Kp, sh.batch,
+                       (long)g.Kp, partial + g.sU, accumulate);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+static int shared_step_b(float* W, const float* partial, float* colsumW, float* hscale, int F, int K, hipStream_t s) {
+    NmfGeom g = make_geom(F, 1, K);
+    return launch_update_w(W, partial, partial + g.sU, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, 0L, 0L, 0L, 0L, 1, s);
+}
+
+static int shared_finish(const SharedShard* sh, int n, float* hscale, int K, hipStream_t s) {
+    for (int i = 0; i < n; ++i) {
+        const NmfGeom& g = sh[i].g;
+        hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(sh[i].batch * g.K), dim3(256), 0, s, sh[i].H, hscale, 0L, g.K, g.sH, g.ld, g.Np);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    const int Kp = gccnmf_round_up(K, 64);
+    hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(Kp, 256)), dim3(256), 0, s, hscale, 1.f, (long)Kp);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// the four-call protocol's workspace: one default-layout shard's scratch | colsumW [Kp] | hscale [Kp]
+static float* legacy_vec(float* ws, const SharedShard& sh) { return sh.rowsum_part + (long)sh.batch * sh.g.Kp; }
+
 long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch) {
-    if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
+    if (!shared_shard_ok(F, N, K, batch, 0)) return -1;
     NmfGeom g = make_geom(F, N, K);
     return (long)batch * (g.sV + g.sU + g.Kp) + 2L * g.Kp;
+}
+
+long gccnmf_klnmf_shared_shard_workspace_floats(int F, int N, int K, int batch, int ld) {
+    if (!shared_shard_ok(F, N, K, batch, ld)) return -1;
+    NmfGeom g = make_geom(F, N, K);
+    return shared_r_floats(g, batch, ld) + (long)batch * (g.sU + g.Kp);
 }
 
 long gccnmf_klnmf_shared_partial_floats(int F, int K) {
@@ -677,57 +759,62 @@ long gccnmf_klnmf_shared_partial_floats(int F, int K) {
 }
 
 int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, int K, int batch, void* stream) {
-    if (!W || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    NmfGeom g = make_geom(F, N, K);
-    SharedWs w = carve_shared(workspace, g, batch);
-    if (hipMemsetAsync(w.R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-    hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 16), dim3(256), 0, s, W, w.colsumW, w.hscale, g.F, g.Fp, g.Kp);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
+    if (!W || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
+    SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
+    float* vec = legacy_vec(workspace, sh);
+    return shared_begin(&sh, 1, W, vec, vec + sh.g.Kp, F, K, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* workspace, float* partial, int F, int N,
                                int K, int batch, float sparsity_alpha, float epsilon, void* stream) {
-    if (!V || !W || !H || !workspace || !partial || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    NmfGeom g = make_geom(F, N, K);
-    SharedWs w = carve_shared(workspace, g, batch);
-    int rc;
-    // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
-    // through that XCD's L2), exactly as the per-file-dictionary path does
-    if ((rc = launch_wh_div(g, V, W, 0, H, w.hscale, 0, w.R, batch, 1, s))) return rc;
-    if ((rc = launch_update_h(g, W, 0, w.R, H, w.hscale, 0, w.colsumW, 0, sparsity_alpha, epsilon, batch, 1, s))) return rc;
-    // (H now carries the previous normalisation; K3 below takes no scale, and step_b rewrites hscale before anyone reads it again)
-    if ((rc = launch_wh_div(g, V, W, 0, H, nullptr, 0, w.R, batch, 1, s))) return rc;
-    if ((rc = launch_rht(g, w.R, H, w.Upart, w.rowsum_part, batch, 1, s))) return rc;
-    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)gccnmf_ceil_div((int)g.sU, 256)), dim3(256), 0, s, w.Upart, g.sU,
-                       batch, g.sU, partial);
-    GCCNMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.rowsum_part, (long)g.Kp,
-                       batch, (long)g.Kp, partial + g.sU);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
+    if (!V || !W || !H || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
+    SharedShard sh = make_shard(V, H, workspace, F, N, K, batch, 0);
+    float* vec = legacy_vec(workspace, sh);
+    return shared_step_a(sh, W, vec, vec + sh.g.Kp, partial, 0, sparsity_alpha, epsilon, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch, void* stream) {
-    if (!W || !workspace || !partial || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    NmfGeom g = make_geom(F, N, K);
-    SharedWs w = carve_shared(workspace, g, batch);
-    return launch_update_w(W, partial, partial + g.sU, w.colsumW, w.hscale, g.F, g.Fp, g.K, g.Kp, 0L, 0L, 0L, 0L, 1, s);
+    if (!W || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
+    SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
+    float* vec = legacy_vec(workspace, sh);
+    return shared_step_b(W, partial, vec, vec + sh.g.Kp, F, K, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream) {
-    if (!H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    if (!H || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
+    SharedShard sh = make_shard(nullptr, H, workspace, F, N, K, batch, 0);
+    float* vec = legacy_vec(workspace, sh);
+    return shared_finish(&sh, 1, vec + sh.g.Kp, K, (hipStream_t)stream);
+}
+
+// The whole shared-dictionary training of one rank in ONE call: begin, `iterations` x (step A of every shard -> all-reduce of
+// `partial` -> step B), finish -- every launch and the collective enqueued on `stream` from C, no host round trip per iteration.
+int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, float* W, float* partial, float* vec, int F, int K,
+                            int iterations, float sparsity_alpha, float epsilon, gccnmf_allreduce_fn allreduce, void* allreduce_ctx,
+                            void* stream) {
+    if (nshards < 0 || nshards > GCCNMF_MAX_SHARDS || (nshards && !shards) || !W || !partial || !vec || F < 2 || K < 1 || iterations < 0)
+        return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    NmfGeom g = make_geom(F, N, K);
-    SharedWs w = carve_shared(workspace, g, batch);
-    hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, w.hscale, 0L, g.K, g.Kp, g.Np);
-    GCCNMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nmf_fill_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, w.hscale, 1.f, (long)g.Kp);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
+    SharedShard sh[GCCNMF_MAX_SHARDS];
+    for (int i = 0; i < nshards; ++i) {
+        const gccnmf_shared_shard& d = shards[i];
+        if (!d.V || !d.H || !d.workspace || !shared_shard_ok(F, d.N, K, d.batch, d.ld)) return GCCNMF_ERR_ARG;
+        sh[i] = make_shard(d.V, d.H, d.workspace, F, d.N, K, d.batch, d.ld);
+    }
+    const NmfGeom g = make_geom(F, 1, K);
+    float *colsumW = vec, *hscale = vec + g.Kp;
+    const long np = g.sU + g.Kp;
+    int rc;
+    if ((rc = shared_begin(sh, nshards, W, colsumW, hscale, F, K, s))) return rc;
+    for (int it = 0; it < iterations; ++it) {
+        // a rank without columns (fewer files than ranks) contributes a zero partial and still follows every W update
+        if (nshards == 0 && hipMemsetAsync(partial, 0, sizeof(float) * np, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        for (int i = 0; i < nshards; ++i)
+            if ((rc = shared_step_a(sh[i], W, colsumW, hscale, partial, i > 0, sparsity_alpha, epsilon, s))) return rc;
+        if (allreduce && allreduce(allreduce_ctx, partial, np, stream) != 0) return GCCNMF_ERR_COLLECTIVE;
+        if ((rc = shared_step_b(W, partial, colsumW, hscale, F, K, s))) return rc;
+    }
+    return shared_finish(sh, nshards, hscale, K, s);
 }
 
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) {

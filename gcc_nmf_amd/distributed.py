@@ -54,9 +54,117 @@ def shared_initial_factors(F, file_columns, K, file_indexes, epsilon=1e-16, seed
     return W.astype(np.float32), Hs
 
 
-class HipSharedNMF(object):
+# ---- how the [num || den] buffer is summed over the ranks inside gccnmf_klnmf_shared_run --------------------------------------------
+# backend "nccl": the library's own RCCL communicator (csrc/collective.hip), created once per process group from a unique id that
+# rank 0 broadcasts over torch.distributed -- the all-reduce is then enqueued from C between the two halves of an iteration, on the
+# compute stream, with no host round trip.  Any other backend (gloo: CPU tests, several ranks rehearsing on one GPU), or
+# GCCNMF_COLLECTIVE=torch: a host callback that runs dist.all_reduce on the same tensor (the C loop calls back once per iteration).
+_rccl_comms = {}
+
+
+def _rccl_comm(group, device):
+    """The library-owned RCCL communicator of (group, device), or None when RCCL cannot be used on EVERY rank."""
+    import ctypes
+    key = (id(group) if group is not None else 0, torch.device(device).index)
+    if key in _rccl_comms:
+        return _rccl_comms[key]
+    lib = _hip.lib()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    ident = torch.zeros(_hip.RCCL_UNIQUE_ID_BYTES + 1, dtype=torch.uint8, device=device)     # [id bytes | ok flag]
+    if rank == 0 and lib.gccnmf_rccl_available():
+        buf = ctypes.create_string_buffer(_hip.RCCL_UNIQUE_ID_BYTES)
+        if lib.gccnmf_rccl_unique_id(buf) == 0:
+            ident[:-1] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(device)
+            ident[-1] = 1
+    dist.broadcast(ident, src=src, group=group)
+    ident = ident.cpu().numpy()
+    flag = torch.tensor([1 if (ident[-1] and lib.gccnmf_rccl_available()) else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    comm = None
+    if int(flag.item()):
+        handle = ctypes.c_void_p()
+        torch.cuda.synchronize(device)
+        with torch.cuda.device(device):
+            ok = lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()):
+            comm = handle.value
+        elif ok:
+            lib.gccnmf_rccl_comm_destroy(handle)
+    _rccl_comms[key] = comm
+    return comm
+
+
+def destroy_rccl_communicators():
+    """Free the library-owned communicators (call before dist.destroy_process_group())."""
+    for comm in _rccl_comms.values():
+        if comm:
+            _hip.lib().gccnmf_rccl_comm_destroy(comm)
+    _rccl_comms.clear()
+
+
+def collective_hook(partial, group=None):
+    """(function pointer, context, keep-alive, description) for gccnmf_klnmf_shared_run's all-reduce of ``partial``."""
+    import ctypes
+    import os
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None, None, None, 'single rank'
+    want = os.environ.get('GCCNMF_COLLECTIVE', '')
+    if want not in ('', 'rccl', 'torch'):
+        raise ValueError('GCCNMF_COLLECTIVE must be rccl or torch, not %r' % want)
+    if want != 'torch' and dist.get_backend(group) == 'nccl':
+        comm = _rccl_comm(group, partial.device)
+        if comm:
+            return _hip.lib().gccnmf_rccl_allreduce_hook(), comm, None, 'rccl (library communicator, enqueued from C)'
+        if want == 'rccl':
+            raise _hip.HipLibraryError('GCCNMF_COLLECTIVE=rccl but librccl could not be bound / initialised on every rank')
+    failure = []
+
+    def allreduce(ctx, buf, count, stream):
+        try:
+            if buf != partial.data_ptr() or count != partial.numel():
+                raise RuntimeError('all-reduce hook called on an unexpected buffer')
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)        # ordered after the kernels on torch's current stream
+            return 0
+        except BaseException as e:                                             # never unwind through the C frame
+            failure.append(e)
+            return 1
+    cb = _hip.ALLREDUCE_FN(allreduce)
+    return ctypes.cast(cb, ctypes.c_void_p).value, None, (cb, failure), 'torch.distributed (%s) host callback' % dist.get_backend(group)
+
+
+class _SharedRun(object):
+    """run(): the whole training of this rank's columns in ONE library call (gccnmf_klnmf_shared_run).  Subclasses provide lib,
+    device, F, K, alpha, eps, Wd, partial, vec and _shards() -> [(V, H, workspace, N, batch, ld)] (device tensors)."""
+
+    @_on_device
+    def run(self, numIterations, group=None):
+        descs = self._shards()
+        arr = (_hip.SharedShard * max(len(descs), 1))()
+        for d, (V, H, ws, N, batch, ld) in zip(arr, descs):
+            d.V, d.H, d.workspace, d.N, d.batch, d.ld = _ptr(V), _ptr(H), _ptr(ws), N, batch, ld
+        fn, ctx, keep, self.collective = collective_hook(self.partial, group)
+        if fn is not None:
+            torch.cuda.current_stream(self.device).synchronize()      # nothing of torch's own collectives is still in flight on the devices
+        rc = self.lib.gccnmf_klnmf_shared_run(arr, len(descs), _ptr(self.Wd), _ptr(self.partial), _ptr(self.vec), self.F, self.K,
+                                              int(numIterations), self.alpha, self.eps, fn, ctx, _stream())
+        if keep is not None and keep[1]:
+            raise keep[1][0]
+        _hip.check(rc, 'gccnmf_klnmf_shared_run')
+        if fn is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+        return self
+
+    def W(self):
+        return self.Wd[:self.F, :self.K].cpu().numpy()
+
+
+class HipSharedNMF(_SharedRun):
     """This rank's shard of a shared-dictionary KL-NMF on the GPU (csrc/nmf.hip, gccnmf_klnmf_shared_*).
-    All local files must have the same number of columns N."""
+    All local files must have the same number of columns N.  ``V_files`` may be EMPTY (a rank without files when there are fewer
+    files than ranks): the rank then contributes zeros to every all-reduce and still applies every W update."""
 
     def __init__(self, V_files, W0, H0_files, sparsityAlpha=0, epsilon=1e-16, device=None):
         if not torch.cuda.is_available():
@@ -65,18 +173,33 @@ class HipSharedNMF(object):
         self.device = torch.device(device if device is not None else ('cuda:%d' % torch.cuda.current_device()))
         V_files = [np.asarray(v, np.float32) for v in V_files]
         self.B = len(V_files)
-        self.F, self.N = V_files[0].shape
-        self.K = W0.shape[1]
+        self.F, self.K = W0.shape
+        self.N = V_files[0].shape[1] if self.B else 0
+        if any(v.shape != (self.F, self.N) for v in V_files) or len(H0_files) != self.B:
+            raise ValueError('every local file needs V of shape (%d, %d) and one H block' % (self.F, self.N))
         self.alpha, self.eps = float(sparsityAlpha), float(epsilon)
-        g = self.g = Geometry(self.F, 1, self.K)
-        self.Np = -(-self.N // 64) * 64
-        dev = self.device
-        self.V = padded(np.stack(V_files), (self.B, g.Fp, self.Np), dev)
+        self._geometry()
+        g, dev = self.g, self.device
+        self.V = padded(np.stack(V_files), (self.B, g.Fp, self.Np), dev) if self.B else None
         self.Wd = padded(np.asarray(W0, np.float32), (g.Fp, g.Kp), dev)
-        self.Hd = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), dev)
-        self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self.N, self.K, self.B), dtype=torch.float32, device=dev)
-        self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=dev)
-        self._W0d, self._H0d = self.Wd.clone(), self.Hd.clone()
+        self.Hd = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), dev) if self.B else None
+        self._scratch()
+        self._W0d, self._H0d = self.Wd.clone(), (self.Hd.clone() if self.B else None)
+
+    def _geometry(self):
+        self.g = Geometry(self.F, 1, self.K)
+        self.Np = -(-self.N // 64) * 64
+        self._gN, self._gB = (self.N, self.B) if self.B else (1, 1)      # the four-call protocol's geometry (a dummy 1 x 1 shard when empty)
+
+    def _scratch(self):
+        # legacy layout: [shard scratch (R | Upart | rowsum_part)] [colsumW | hscale]
+        self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self._gN, self.K, self._gB), dtype=torch.float32,
+                              device=self.device)
+        self.vec = self.ws[self.ws.numel() - 2 * self.g.Kp:]
+        self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=self.device)
+
+    def _shards(self):
+        return [(self.V, self.Hd, self.ws, self.N, self.B, 0)] if self.B else []
 
     @classmethod
     def from_device(cls, V_dev, F, N, W0, H0_files, sparsityAlpha=0, epsilon=1e-16):
@@ -86,15 +209,13 @@ class HipSharedNMF(object):
         self.device = V_dev.device
         self.B, self.F, self.N, self.K = V_dev.shape[0], int(F), int(N), W0.shape[1]
         self.alpha, self.eps = float(sparsityAlpha), float(epsilon)
-        g = self.g = Geometry(self.F, 1, self.K)
-        self.Np = -(-self.N // 64) * 64
+        self._geometry()
+        g = self.g
         assert tuple(V_dev.shape) == (self.B, g.Fp, self.Np)
         self.V = V_dev
         self.Wd = torch.zeros((g.Fp, g.Kp), dtype=torch.float32, device=self.device)
         self.Hd = torch.zeros((self.B, g.Kp, self.Np), dtype=torch.float32, device=self.device)
-        self.ws = torch.zeros(self.lib.gccnmf_klnmf_shared_workspace_floats(self.F, self.N, self.K, self.B), dtype=torch.float32,
-                              device=self.device)
-        self.partial = torch.zeros(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K), dtype=torch.float32, device=self.device)
+        self._scratch()
         self.reset(W0, H0_files)
         return self
 
@@ -105,20 +226,25 @@ class HipSharedNMF(object):
         g = self.g
         if W0 is not None:
             self._W0d = padded(np.asarray(W0, np.float32), (g.Fp, g.Kp), self.device)
-        if H0_files is not None:
+        if H0_files is not None and self.B:
             self._H0d = padded(np.stack([np.asarray(h, np.float32) for h in H0_files]), (self.B, g.Kp, self.Np), self.device)
-        if not hasattr(self, '_W0d') or not hasattr(self, '_H0d'):
+        if not hasattr(self, '_W0d') or (self.B and getattr(self, '_H0d', None) is None):
             raise ValueError('reset() without arguments needs initial factors from an earlier reset(W0, H0_files)')
         self.Wd.copy_(self._W0d)
-        self.Hd.copy_(self._H0d)
+        if self.B:
+            self.Hd.copy_(self._H0d)
 
+    # the four-call protocol (one all-reduce between step_a and step_b, driven by the host): kept for hosts that own the collective
     @_on_device
     def begin(self):
-        _hip.check(self.lib.gccnmf_klnmf_shared_begin(_ptr(self.Wd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
+        _hip.check(self.lib.gccnmf_klnmf_shared_begin(_ptr(self.Wd), _ptr(self.ws), self.F, self._gN, self.K, self._gB, _stream()),
                    'gccnmf_klnmf_shared_begin')
 
     @_on_device
     def step_a(self):
+        if not self.B:
+            self.partial.zero_()
+            return self.partial
         _hip.check(self.lib.gccnmf_klnmf_shared_step_a(_ptr(self.V), _ptr(self.Wd), _ptr(self.Hd), _ptr(self.ws), _ptr(self.partial),
                                                        self.F, self.N, self.K, self.B, self.alpha, self.eps, _stream()),
                    'gccnmf_klnmf_shared_step_a')
@@ -126,25 +252,60 @@ class HipSharedNMF(object):
 
     @_on_device
     def step_b(self, partial):
-        _hip.check(self.lib.gccnmf_klnmf_shared_step_b(_ptr(self.Wd), _ptr(self.ws), _ptr(partial), self.F, self.N, self.K, self.B,
+        _hip.check(self.lib.gccnmf_klnmf_shared_step_b(_ptr(self.Wd), _ptr(self.ws), _ptr(partial), self.F, self._gN, self.K, self._gB,
                                                        _stream()), 'gccnmf_klnmf_shared_step_b')
 
     @_on_device
     def finish(self):
-        _hip.check(self.lib.gccnmf_klnmf_shared_finish(_ptr(self.Hd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
-                   'gccnmf_klnmf_shared_finish')
-
-    def W(self):
-        return self.Wd[:self.F, :self.K].cpu().numpy()
+        if self.B:
+            _hip.check(self.lib.gccnmf_klnmf_shared_finish(_ptr(self.Hd), _ptr(self.ws), self.F, self.N, self.K, self.B, _stream()),
+                       'gccnmf_klnmf_shared_finish')
 
     def H(self):
-        return [h[:self.K, :self.N].cpu().numpy() for h in self.Hd]
+        return [h[:self.K, :self.N].cpu().numpy() for h in self.Hd] if self.B else []
+
+
+class HipSharedColumns(_SharedRun):
+    """The columns of ONE matrix pair V [Fp][ld] / H [Kp][ld] (device tensors, padding zero) as this rank's part of a shared-dictionary
+    KL-NMF, without copying them: the N columns are handed to the batched kernels as column BLOCKS of ``block`` columns (a multiple of 64)
+    plus one ragged remainder (gccnmf_shared_shard with ld > 0).  The partition does not change the update (gccNMFFunctions.py:76 is
+    column-local, :77 sums over all columns); it only sets how many workgroups the R.H^T launch has (16 per block at K = 1024)."""
+
+    def __init__(self, V, H, W, F, N, K, sparsityAlpha=0, epsilon=1e-16, block=None):
+        self.lib = _hip.lib()
+        self.device = V.device
+        self.F, self.N, self.K = int(F), int(N), int(K)
+        self.alpha, self.eps = float(sparsityAlpha), float(epsilon)
+        g = self.g = Geometry(self.F, 1, self.K)
+        self.ld = V.shape[1]
+        assert tuple(V.shape) == (g.Fp, self.ld) and tuple(H.shape) == (g.Kp, self.ld) and tuple(W.shape) == (g.Fp, g.Kp)
+        assert self.ld % 64 == 0 and self.ld >= self.N and V.is_contiguous() and H.is_contiguous() and W.is_contiguous()
+        self.V, self.Hd, self.Wd = V, H, W
+        if block is None:
+            # R.H^T has Kp/64 workgroups per block: aim at >= 512 (two per CU), blocks of at least 256 columns (16 k-tiles)
+            want = max(1, -(-512 // (g.Kp // 64)))
+            block = max(256, 64 * (self.N // (64 * want)))
+        if block % 64:
+            raise ValueError('column blocks must be multiples of 64 columns')
+        self.block = int(block)
+        nb, rem = divmod(self.N, self.block)
+        self.blocks = ([(0, self.block, nb)] if nb else []) + ([(nb * self.block, rem, 1)] if rem else [])    # (first column, width, count)
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._ws = [z(self.lib.gccnmf_klnmf_shared_shard_workspace_floats(self.F, width, self.K, count, self.ld)) for _, width, count in self.blocks]
+        self.partial = z(self.lib.gccnmf_klnmf_shared_partial_floats(self.F, self.K))
+        self.vec = z(2 * g.Kp)
+
+    def _shards(self):
+        return [(self.V[:, c0:], self.Hd[:, c0:], ws, width, count, self.ld) for (c0, width, count), ws in zip(self.blocks, self._ws)]
+
+    def H(self):
+        return [self.Hd[:self.K, :self.N].cpu().numpy()]
 
 
 class CompositeSharedNMF(object):
     """Several shards of one rank behind the begin / step_a / step_b / finish protocol: their [num || den] partials are added (fixed
-    order) before the all-reduce and every member applies the same reduced buffer.  Lets one rank hold column blocks of different
-    widths (``HipSharedNMF`` needs equal N per object): e.g. the equal blocks of a long mixture plus its ragged remainder."""
+    order) before the all-reduce and every member applies the same reduced buffer.  Lets one rank hold file groups of different
+    widths (``HipSharedNMF`` needs equal N per object)."""
 
     def __init__(self, members):
         self.members = list(members)
@@ -174,9 +335,12 @@ class CompositeSharedNMF(object):
 
 
 def train_shared_dictionary(local, numIterations, group=None):
-    """The shared-dictionary iteration, identical on every rank.  ``local`` owns this rank's columns and provides
-    begin() / step_a() -> partial tensor [num (Fp*Kp) || den (Kp)] / step_b(partial) / finish().
-    One all-reduce per iteration; with a single process (or no process group) it degenerates to plain KL-NMF."""
+    """The shared-dictionary iteration, identical on every rank: one all-reduce of [num (Fp*Kp) || den (Kp)] per iteration; with a
+    single process (or no process group) it degenerates to plain KL-NMF.  A ``local`` with run() (the HIP shards) does the whole
+    loop inside the library -- kernels and collective enqueued from C; otherwise ``local`` provides begin() / step_a() -> partial
+    tensor / step_b(partial) / finish() and the loop is driven from here (the NumPy oracle shards of the CPU tests)."""
+    if hasattr(local, 'run'):
+        return local.run(numIterations, group)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     local.begin()
     for _ in range(int(numIterations)):
@@ -255,11 +419,12 @@ def stitch_time_shards(segments, numTargets, total_frames, hop):
 
 class HipTimeShard(object):
     """This rank's frames [t0, t1) of one long mixture on the GPU: a batch-1 ``GCCNMFEngine`` over the rank's sample range plus a
-    ``HipSharedNMF`` on its magnitude spectrogram.  ``stereoSamples`` is the WHOLE (2, n) mixture (only the own range is uploaded)."""
+    ``HipSharedColumns`` on its magnitude spectrogram (column blocks of the engine's own V / H: the NMF runs in place).
+    ``stereoSamples`` is the WHOLE (2, n) mixture (only the own range is uploaded)."""
 
     def __init__(self, stereoSamples, rank, world_size, sampleRate=16000, windowSize=1024, hopSize=256, numTDOAs=128,
                  microphoneSeparationInMetres=1.0, numTargets=3, dictionarySize=128, sparsityAlpha=0, epsilon=1e-16, seedValue=0,
-                 device=None):
+                 device=None, block=None):
         from .engine import GCCNMFEngine, num_frames
         x = np.asarray(stereoSamples, np.float32)
         self.n_fft, self.hop, self.S = int(windowSize), int(hopSize), int(numTargets)
@@ -279,59 +444,23 @@ class HipTimeShard(object):
         assert e.g.T == Tr
         self.device = e.device
         e.upload(x[:, lo:hi])
-        self._W0, self._H0 = time_shard_initial_factors(e.g.F, self.T_total, e.g.K, self.t0, self.t1, epsilon, seedValue)
-        self._alpha, self._eps = sparsityAlpha, epsilon
-        self.nmf = None
-
-    # The rank's 2*T_r NMF columns are handed to the batched kernels as pseudo-files of BLOCK frames ([left | right] columns of those
-    # frames, the layout of one 10 s file) plus one ragged remainder: the per-file launches then fill the chip (a single "file" of
-    # 20 000 columns would leave R.H^T with 16 workgroups of 1 250 k-tiles), and the column partition does not change the update
-    # (gccNMFFunctions.py:76 is column-local, :77 sums over all columns).
-    BLOCK = 640
-
-    def _blocks(self):
-        Tr = self.e.g.T
-        nb, rem = divmod(Tr, self.BLOCK)
-        out = [(j * self.BLOCK, self.BLOCK) for j in range(nb)]
-        if rem:
-            out.append((nb * self.BLOCK, rem))
-        return out                                               # [(first frame, frames)]
-
-    def _gather(self, src, T0, Tb, Np_b, rows):
-        """columns [T0, T0+Tb) of both channel halves of a [rows][Np] matrix -> one [rows][Np_b] block"""
-        Tr = self.e.g.T
-        blk = torch.zeros((rows, Np_b), dtype=torch.float32, device=self.device)
-        blk[:, :Tb] = src[:, T0:T0 + Tb]
-        blk[:, Tb:2 * Tb] = src[:, Tr + T0:Tr + T0 + Tb]
-        return blk
+        W0, H0 = time_shard_initial_factors(e.g.F, self.T_total, e.g.K, self.t0, self.t1, epsilon, seedValue)
+        g = e.g
+        with torch.cuda.device(self.device):
+            self._W0d = padded(W0, (g.Fp, g.Kp), self.device)
+            self._H0d = padded(H0, (g.Kp, g.Np), self.device)          # [left frames | right frames], the layout of e.V / e.H
+            # The rank's 2*T_r NMF columns stay where the STFT put them (e.V[0]) and where the mask stages read them (e.W[0], e.H[0]):
+            # the shared-dictionary kernels take them as column blocks of those matrices (no gather / scatter, no second copy).
+            self.nmf = HipSharedColumns(e.V[0], e.H[0], e.W[0], g.F, g.N, g.K, sparsityAlpha, epsilon, block=block)
 
     @_on_device
     def stft(self):
-        e, g = self.e, self.e.g
-        e.stft()
-        H0 = torch.zeros((g.Kp, g.Np), dtype=torch.float32, device=self.device)
-        H0[:g.K, :g.N] = torch.from_numpy(self._H0).to(self.device)
-        members, self._groups = [], []
-        blocks = self._blocks()
-        for width in sorted(set(tb for _, tb in blocks), reverse=True):
-            mine = [(t0, tb) for t0, tb in blocks if tb == width]
-            Np_b = -(-2 * width // 64) * 64
-            V = torch.stack([self._gather(e.V[0], t0, tb, Np_b, g.Fp) for t0, tb in mine])
-            shard = HipSharedNMF.from_device(V, g.F, 2 * width, self._W0, [np.zeros((g.K, 2 * width), np.float32)] * len(mine), self._alpha, self._eps)
-            shard.Hd.copy_(torch.stack([self._gather(H0, t0, tb, Np_b, g.Kp) for t0, tb in mine]))
-            shard._H0d = shard.Hd.clone()
-            members.append(shard)
-            self._groups.append(mine)
-        self.nmf = CompositeSharedNMF(members)
+        self.e.stft()
+        self.e.W[0].copy_(self._W0d)
+        self.e.H[0].copy_(self._H0d)
 
-    @_on_device
     def nmf_done(self):
-        e, Tr = self.e, self.e.g.T
-        e.W[0].copy_(self.nmf.members[0].Wd)
-        for shard, mine in zip(self.nmf.members, self._groups):
-            for j, (t0, tb) in enumerate(mine):
-                e.H[0][:, t0:t0 + tb] = shard.Hd[j][:, :tb]
-                e.H[0][:, Tr + t0:Tr + t0 + tb] = shard.Hd[j][:, tb:2 * tb]
+        pass                                                         # W and H were updated in place in the engine's buffers
 
     @_on_device
     def angular_sum(self):

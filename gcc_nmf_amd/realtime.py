@@ -63,6 +63,12 @@ class GCCNMFProcessor(object):
         self.microphoneSeparationInMetres = microphoneSeparationInMetres
         self.localizationEnabled, self.localizationWindowSize = localizationEnabled, int(localizationWindowSize)
         self.numTDOAs, self.numTDOAHistory = int(numTDOAs), int(numTDOAHistory)
+        # host mirrors for the GUI (gccNMFProcessor.py:180-184): any object with SharedMemoryCircularBuffer's set() (utils.py:34-70);
+        # filled after every call from ONE small download of the device state (:211-229)
+        self.gccPHATHistory, self.tdoaHistory = gccPHATHistory, tdoaHistory
+        self.inputSpectrogramHistory, self.outputSpectrogramHistory = inputSpectrogramHistory, outputSpectrogramHistory
+        self.coefficientMaskHistories = coefficientMaskHistories
+        self.generation = 0
         self.separationEnabled = True
         self.targetMode = TARGET_MODE_WINDOW_FUNCTION
         self.windowFunction = np.sqrt(np.hamming(self.windowSize).astype(np.float32))[:, np.newaxis]      # :186
@@ -81,6 +87,7 @@ class GCCNMFProcessor(object):
     def reset(self):
         """:233-270 (buildTheanoFunctions): tables and buffers for the current dictionary / TDOA grid."""
         dev = self.device
+        self.generation += 1              # every device buffer below is re-allocated: captured graphs that hold the old pointers are stale
         self.W = np.asarray(self.dictionariesW[self.dictionaryType][self.dictionarySize], np.float32)
         self.numFrequencies, self.numAtom = self.W.shape
         if self.numFrequencies != self.windowSize // 2 + 1:
@@ -100,11 +107,18 @@ class GCCNMFProcessor(object):
         self.dColsum = padded(self.W.sum(axis=0, dtype=np.float32), (self.Kp,), dev)          # sum_f W: denominator of the H update
         self.dHcoef, self.dRv = z(self.Kp, Tc, 2), z(F, Tc, 2)
         self.dTwiddle = torch.from_numpy(fft_twiddles(self.windowSize)).to(dev)
-        self.dX, self.dY, self.dC = z(2, F, Tc, 2), z(2, F, Tc, 2), z(F, Tc, 2)
-        self.dHMask, self.dArgmax = z(self.Kp, Tc), z(self.Kp, Tc, dtype=torch.int32)
-        self.dTfMask, self.dGccPhat = z(2, F, Tc), z(D, Tc)          # tfMask: [F][Tc] used without coefficient inference, [2][F][Tc] with
+        # what the host mirrors are computed from lives in ONE block, so that they cost one download per call: X | Y | HMask | gccPHAT | target
+        sizes = [2 * F * Tc * 2, 2 * F * Tc * 2, self.Kp * Tc, D * Tc, 4]
+        offs = np.concatenate([[0], np.cumsum([-(-n // 4) * 4 for n in sizes])])
+        self.dMirror = z(int(offs[-1]))
+        part = lambda i, *shape: self.dMirror[int(offs[i]):int(offs[i]) + sizes[i]].view(*shape)
+        self.dX, self.dY, self.dC = part(0, 2, F, Tc, 2), part(1, 2, F, Tc, 2), z(F, Tc, 2)
+        self.dHMask, self.dArgmax = part(2, self.Kp, Tc), z(self.Kp, Tc, dtype=torch.int32)
+        self.dTfMask, self.dGccPhat = z(2, F, Tc), part(3, D, Tc)     # tfMask: [F][Tc] used without coefficient inference, [2][F][Tc] with
         self.dHist, self.dHistPos = z(D, self.numTDOAHistory), z(1, dtype=torch.int32)
-        self.dTarget = torch.from_numpy(self._target_host.copy()).to(dev)
+        self.dTarget = part(4, 4)
+        self.dTarget.copy_(torch.from_numpy(self._target_host))
+        self._mirror_offs, self._mirror_sizes, self._mirror_host = offs, sizes, None
         self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
 
     @_on_device
@@ -138,7 +152,41 @@ class GCCNMFProcessor(object):
         self.dFramesIn.copy_(torch.from_numpy(np.ascontiguousarray(ws.transpose(0, 2, 1))))
         # hop = windowSize, block = Tc * windowSize describes Tc back-to-back frames to the kernels' start0/step arithmetic
         self._call(None, None, self.dFramesIn, self.dFramesOut, self.windowSize, Tc * self.windowSize, 1)
-        return self.dFramesOut.cpu().numpy().transpose(0, 2, 1)
+        out = self.dFramesOut.cpu().numpy().transpose(0, 2, 1)
+        self.fill_histories()
+        return out
+
+    def wants_histories(self):
+        return any(h is not None for h in (self.gccPHATHistory, self.tdoaHistory, self.inputSpectrogramHistory,
+                                           self.outputSpectrogramHistory)) or bool(self.coefficientMaskHistories)
+
+    @_on_device
+    def fill_histories(self):
+        """The reference's history updates (:211-229) from the state the last device call left: one download of dMirror, then its own
+        NumPy expressions on X, Y, HMask and gccPHAT.  The TDOA tracking itself already ran on the device (history ring + arg-max,
+        csrc/rt.hip); ``tdoaHistory`` receives the index it picked.  No-op when no history object was given."""
+        if not self.wants_histories():
+            return
+        if self._mirror_host is None:
+            self._mirror_host = torch.zeros(self.dMirror.shape, dtype=torch.float32).pin_memory()
+        self._mirror_host.copy_(self.dMirror, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        m, o, n = self._mirror_host.numpy(), self._mirror_offs, self._mirror_sizes
+        F, Tc, K, D = self.numFrequencies, self.numTimePerChunk, self.numAtom, self.numTDOAs
+        cplx = lambda i: m[o[i]:o[i] + n[i]].reshape(2, F, Tc, 2).copy().view(np.complex64)[..., 0]
+        X = cplx(0)
+        if self.separationEnabled and self.coefficientMaskHistories:
+            self.coefficientMaskHistories[self.dictionarySize].set(1 - m[o[2]:o[2] + n[2]].reshape(self.Kp, Tc)[:K])          # :211-212
+        if self.inputSpectrogramHistory is not None:
+            self.inputSpectrogramHistory.set(-np.mean(np.abs(X), axis=0) ** (1 / 3.0))                                      # :216-217
+        if self.gccPHATHistory is not None:
+            self.gccPHATHistory.set(m[o[3]:o[3] + n[3]].reshape(D, Tc).copy())                                                 # :218-219
+        if self.tdoaHistory is not None:
+            self.tdoaHistory.set(np.array([[np.float32(m[o[4]])]]))                                                            # :220-227
+        if self.outputSpectrogramHistory is not None:
+            Y = cplx(1) if self.separationEnabled else X                                                                      # :213-214
+            with np.errstate(invalid='ignore'):
+                self.outputSpectrogramHistory.set(-np.nanmean(np.abs(Y), axis=0) ** (1 / 3.0))                                # :228-229
 
     # ---- device results of the last call, in the reference's shapes --------------------------------------------------
     @_on_device
@@ -161,6 +209,17 @@ class StreamingGCCNMF(object):
         if outputDelayBlocks not in (1, 2, 3, 4, 5, 6, 7):
             raise ValueError('outputDelayBlocks must be 1..7')
         self.outputDelayBlocks = int(outputDelayBlocks)
+        # The block handed out is complete only when no later frame adds into it: the synthesis window's non-zero support (first
+        # non-zero sample to the end of the frame) must fit in outputDelayBlocks * blockSize + hopSize samples.  2 is the reference's
+        # hand-out whatever the window (utils.py:116 -- with its own 512 / 64 low-latency setting it hands out partial sums, and
+        # the goldens pin that); any other delay must be complete.
+        if self.outputDelayBlocks != 2:
+            nz = np.nonzero(np.asarray(processor.synthesisWindowFunction).reshape(-1))[0]
+            support = processor.windowSize - int(nz[0]) if len(nz) else 0
+            if support > self.outputDelayBlocks * int(blockSize) + int(hopSize):
+                raise ValueError('outputDelayBlocks=%d hands a block out before it is complete: the synthesis window spans %d samples, '
+                                 'at most %d fit (use asymmetricWindows, or the reference\'s delay of 2)'
+                                 % (self.outputDelayBlocks, support, self.outputDelayBlocks * int(blockSize) + int(hopSize)))
         if blockSize % hopSize or blockSize // hopSize != processor.numTimePerChunk:
             raise ValueError('blockSize/hopSize must equal the processor\'s numTimePerChunk')
         if blockSize > 512 or 8 * blockSize < processor.windowSize + (processor.numTimePerChunk - 1) * hopSize:
@@ -191,7 +250,7 @@ class StreamingGCCNMF(object):
             self._pin_in.copy_(torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)))
             # everything the captured launches depend on besides buffer contents: re-capture when one of them changes
             key = (int(p.targetMode), bool(p.separationEnabled), bool(p.localizationEnabled), int(p.localizationWindowSize),
-                   int(p.numHUpdates), p.dW.data_ptr(), p.dTarget.data_ptr())
+                   int(p.numHUpdates), p.dW.data_ptr(), p.dTarget.data_ptr(), p.generation)      # reset() re-allocates every buffer
             if self.use_graph and self._graph_key != key:
                 self._graph, self._graph_key = self._capture(), key
             if self._graph is not None:
@@ -201,7 +260,9 @@ class StreamingGCCNMF(object):
             self._ev_out.record()
             p._call(self.block_in, self.block_out, self.in_ring, self.out_ring, self.hopSize, self.blockSize, 4, self.outputDelayBlocks)
             self._ev_out.synchronize()
-        return self._pin_out.numpy().copy()
+            out = self._pin_out.numpy().copy()
+            p.fill_histories()                 # host mirrors (only when history objects were given): after the tracking update
+        return out
 
     def _launch_front(self):
         self.block_in.copy_(self._pin_in, non_blocking=True)
@@ -209,7 +270,8 @@ class StreamingGCCNMF(object):
         self._pin_out.copy_(self.block_out, non_blocking=True)
 
     def _capture(self):
-        """upload -> kernels (all but the tracking update) -> download as one HIP graph; None if capture is not possible here."""
+        """upload -> kernels (all but the tracking update) -> download as one HIP graph.  A failed capture is not silent: it is kept in
+        ``capture_error`` and warned about once (the direct launches are correct but ~2x the p99 latency); use_graph=False opts out."""
         try:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -220,8 +282,14 @@ class StreamingGCCNMF(object):
             for t, s0 in zip((self.in_ring, self.out_ring, self.p.dHist, self.p.dHistPos, self.p.dTarget), state):
                 t.copy_(s0)
             torch.cuda.synchronize()
+            self.capture_error = None
             return g
-        except Exception:
+        except Exception as e:
+            import warnings
+            if getattr(self, 'capture_error', None) is None:
+                warnings.warn('StreamingGCCNMF: HIP graph capture failed (%s: %s); falling back to direct launches' % (type(e).__name__, e),
+                              RuntimeWarning)
+            self.capture_error = e
             return None
 
     def process_stream(self, stereoSamples):

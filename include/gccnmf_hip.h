@@ -33,6 +33,7 @@ extern "C" {
 #define GCCNMF_ERR_ARG 1
 #define GCCNMF_ERR_LAUNCH 2
 #define GCCNMF_ERR_UNSUPPORTED 3
+#define GCCNMF_ERR_COLLECTIVE 4   /* the all-reduce hook of gccnmf_klnmf_shared_run (or RCCL behind gccnmf_rccl_*) failed */
 
 /* flags for gccnmf_klnmf */
 #define GCCNMF_FLAG_NO_XCD_AFFINITY 1   /* plain file-major block order instead of the XCD-affine map */
@@ -45,7 +46,11 @@ int gccnmf_version(void);
  * 16 no epilogue.  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
  * 2 always the 128x64 small-batch tile (results stay valid; used by the tests to cover both paths at any size).
  * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
- * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs). */
+ * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs).
+ * key 4: 1 (default) = small launches run on the LDS-DMA ring kernel (csrc/gemm_ring.h).  keys 5 / 6: parts of the single-file
+ * split-K reductions (W.H / R.H^T).  key 7: 1 = the throughput tile's V / (W.H) epilogue divides IEEE-exactly like numpy.divide
+ * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
+ * small-launch kernels always divide exactly).  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -112,6 +117,49 @@ int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* 
 int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch,
                                void* stream);
 int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream);
+
+/* The same training as ONE call per rank: begin, `iterations` x (step A of every shard -> all-reduce -> step B), finish, all
+ * enqueued on `stream` from C -- no host round trip per iteration (gccnmf_klnmf_shared_step(..., ncclComm_t)).
+ * A rank's columns are given as up to GCCNMF_MAX_SHARDS shards of `batch` equally wide files each:
+ *   ld == 0  whole padded matrices back to back: V [batch][Fp][Np], H [batch][Kp][Np]  (the layout of every other entry point)
+ *   ld  > 0  column blocks of ONE matrix with row pitch ld: file b = columns [b*N, b*N + N) of V [Fp][ld] / H [Kp][ld]
+ *            (N a multiple of 64 unless batch == 1; batch*N <= ld; columns beyond a ragged block's N up to the next multiple
+ *            of 64 must be allocated and zero) -- the frame windows of one long mixture without gather / scatter.
+ *   workspace: gccnmf_klnmf_shared_shard_workspace_floats(F, N, K, batch, ld) floats of scratch per shard.
+ * nshards == 0 is a rank without columns (fewer files than ranks): it contributes zeros and still applies every W update.
+ *   W [Fp][Kp] in/out (identical on every rank on entry -> identical on exit), partial: gccnmf_klnmf_shared_partial_floats
+ *   floats, vec: 2*Kp floats of scratch.  The shards' partial sums are added in shard order (deterministic).
+ * allreduce: sums `count` floats of `buf` (device memory) in place over all ranks, ordered on `stream`; returns 0 on success.
+ *   NULL = single rank.  gccnmf_rccl_allreduce below is the RCCL implementation; any other transport (MPI, a host callback that
+ *   runs torch.distributed over gloo ...) has the same signature. */
+#define GCCNMF_MAX_SHARDS 8
+typedef struct gccnmf_shared_shard {
+    const float* V;
+    float* H;
+    float* workspace;
+    int N, batch, ld;
+} gccnmf_shared_shard;
+typedef int (*gccnmf_allreduce_fn)(void* ctx, float* buf, long count, void* stream);
+long gccnmf_klnmf_shared_shard_workspace_floats(int F, int N, int K, int batch, int ld);
+int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, float* W, float* partial, float* vec, int F, int K,
+                            int iterations, float sparsity_alpha, float epsilon, gccnmf_allreduce_fn allreduce, void* allreduce_ctx,
+                            void* stream);
+
+/* RCCL binding for the hook above (csrc/collective.hip).  librccl.so.1 is bound at run time with dlopen (the copy already
+ * loaded into the process, e.g. PyTorch's, else the system one): the library loads without RCCL, these calls then return
+ * GCCNMF_ERR_COLLECTIVE.  One process per GPU: rank 0 calls gccnmf_rccl_unique_id and hands the 128 bytes to every rank
+ * (any out-of-band channel), every rank calls gccnmf_rccl_comm_init with the device it computes on current.
+ *   gccnmf_rccl_allreduce(comm, buf, count, stream): ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, comm, stream) --
+ *   pass it as `allreduce` with allreduce_ctx = comm.  The reference has no collectives; this is the exchange
+ *   of the shared-dictionary W update (gccNMFFunctions.py:77 summed over every rank's columns). */
+#define GCCNMF_RCCL_UNIQUE_ID_BYTES 128
+int gccnmf_rccl_available(void);
+int gccnmf_rccl_unique_id(char* id_bytes);
+int gccnmf_rccl_comm_init(const char* id_bytes, int world_size, int rank, void** comm);
+int gccnmf_rccl_comm_destroy(void* comm);
+int gccnmf_rccl_allreduce(void* comm, float* buf, long count, void* stream);
+/* the address of gccnmf_rccl_allreduce as a gccnmf_allreduce_fn (for hosts that cannot take a symbol's address, e.g. ctypes) */
+gccnmf_allreduce_fn gccnmf_rccl_allreduce_hook(void);
 
 /* GCC-PHAT angular spectrogram A[tau][t] = sum_f Re(C[f,t] exp(-2j pi f tau)) as a real GEMM
  * [cos;sin]^T . [Re C; Im C], plus its time mean.  Replaces getAngularSpectrogram

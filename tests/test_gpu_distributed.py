@@ -18,6 +18,21 @@ def _problem(F, K, cols, seed=1):
     return [(np.abs(rng.standard_normal((F, n))) + 0.05).astype(np.float32) for n in cols]
 
 
+def _protocol(shards, iters):
+    """The four-call protocol driven from the host; the all-reduce over ranks is the explicit sum of the shards' partial buffers."""
+    for s in shards:
+        s.begin()
+    for _ in range(iters):
+        parts = [s.step_a() for s in shards]
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total += p
+        for s in shards:
+            s.step_b(total)
+    for s in shards:
+        s.finish()
+
+
 @pytest.mark.parametrize('F,K,N,B,alpha', [(513, 128, 100, 4, 0), (257, 64, 70, 3, 0.2), (513, 1024, 130, 9, 0)])
 def test_shared_dictionary_matches_performKLNMF_on_concatenation(F, K, N, B, alpha):
     from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
@@ -40,20 +55,99 @@ def test_two_shards_one_exchange():
         mine = shard_files(B, 2, rank)
         W0, H0 = shared_initial_factors(F, [N] * B, K, mine, mode='concat')
         shards.append(HipSharedNMF([V[i] for i in mine], W0, H0))
-    for s in shards:
-        s.begin()
-    for _ in range(6):
-        parts = [s.step_a() for s in shards]
-        total = parts[0] + parts[1]                  # == dist.all_reduce(SUM) over two ranks
-        for s in shards:
-            s.step_b(total.clone())
-    for s in shards:
-        s.finish()
+    _protocol(shards, 6)                             # the sum of the two partials == dist.all_reduce(SUM) over two ranks
     assert np.array_equal(shards[0].W(), shards[1].W())
     Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 6, 0)
     H = np.concatenate(shards[0].H() + shards[1].H(), axis=1)
     assert np.linalg.norm(shards[0].W() - Wr) < 1e-4 * np.linalg.norm(Wr)
     assert np.linalg.norm(H - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
+def test_one_call_run_is_bitwise_the_four_call_protocol():
+    """gccnmf_klnmf_shared_run (the loop inside the library) against begin / step_a / step_b / finish driven from the host."""
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors
+    F, K, N, B = 513, 128, 100, 4
+    V = _problem(F, K, [N] * B, seed=7)
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    a, b = HipSharedNMF(V, W0, H0, sparsityAlpha=0.1), HipSharedNMF(V, W0, H0, sparsityAlpha=0.1)
+    _protocol([a], 7)
+    b.run(7)
+    assert b.collective == 'single rank'
+    assert np.array_equal(a.W(), b.W())
+    assert all(np.array_equal(x, y) for x, y in zip(a.H(), b.H()))
+
+
+def test_rank_without_files_contributes_zeros():
+    """3 files over 4 ranks (shard_files leaves rank 3 empty): the empty shard adds a zero partial and follows every W update."""
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, shard_files
+    F, K, N, B, world = 257, 64, 70, 3, 4
+    V = _problem(F, K, [N] * B, seed=9)
+    shards = []
+    for rank in range(world):
+        mine = shard_files(B, world, rank)
+        W0, H0 = shared_initial_factors(F, [N] * B, K, mine, mode='concat')
+        shards.append(HipSharedNMF([V[i] for i in mine], W0, H0))
+    assert shards[3].B == 0 and shards[3].H() == []
+    _protocol(shards, 6)
+    assert all(np.array_equal(shards[0].W(), s.W()) for s in shards[1:])
+    Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 6, 0)
+    assert np.linalg.norm(shards[3].W() - Wr) < 1e-4 * np.linalg.norm(Wr)
+    H = np.concatenate(sum([s.H() for s in shards], []), axis=1)
+    assert np.linalg.norm(H - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
+@pytest.mark.parametrize('N,block', [(1000, 256), (1244, None), (640, 320), (200, 256)])
+def test_column_blocks_of_one_matrix(N, block):
+    """HipSharedColumns: the columns of ONE matrix as column blocks + ragged remainder, in place (ld > 0 shards) == performKLNMF."""
+    from gcc_nmf_amd.distributed import HipSharedColumns
+    from gcc_nmf_amd.engine import Geometry, klnmf_initial_factors, padded
+    F, K, iters = 513, 128, 8
+    V = _problem(F, K, [N], seed=N)[0]
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    g = Geometry(F, 1, K)
+    ld = -(-N // 64) * 64
+    Vd, Hd, Wd = padded(V, (g.Fp, ld), 'cuda'), padded(H0, (g.Kp, ld), 'cuda'), padded(W0, (g.Fp, g.Kp), 'cuda')
+    nmf = HipSharedColumns(Vd, Hd, Wd, F, N, K, block=block)
+    assert sum(w * c for _, w, c in nmf.blocks) == N
+    nmf.run(iters)
+    Wr, Hr = O.performKLNMF(V, K, iters, 0)
+    assert np.linalg.norm(nmf.W() - Wr) < 1e-4 * np.linalg.norm(Wr)
+    assert np.linalg.norm(nmf.H()[0] - Hr) < 1e-4 * np.linalg.norm(Hr)
+    assert float(Hd[:, N:].abs().max()) == 0.0 and float(Hd[K:].abs().max()) == 0.0 if ld > N else True      # padding untouched
+
+
+def test_library_rccl_communicator_single_rank():
+    """csrc/collective.hip on hardware: librccl bound by dlopen, a 1-rank communicator from a unique id, ncclAllReduce enqueued from C
+    inside gccnmf_klnmf_shared_run -- same bits as the run without a collective."""
+    import ctypes
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors
+    from gcc_nmf_amd.engine import _ptr, _stream
+    lib = _hip.lib()
+    assert lib.gccnmf_rccl_available() == 1
+    ident = ctypes.create_string_buffer(_hip.RCCL_UNIQUE_ID_BYTES)
+    _hip.check(lib.gccnmf_rccl_unique_id(ident), 'gccnmf_rccl_unique_id')
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    _hip.check(lib.gccnmf_rccl_comm_init(ident.raw, 1, 0, ctypes.byref(comm)), 'gccnmf_rccl_comm_init')
+    try:
+        t = torch.arange(4096, dtype=torch.float32, device='cuda')
+        _hip.check(lib.gccnmf_rccl_allreduce(comm, _ptr(t), t.numel(), _stream()), 'gccnmf_rccl_allreduce')
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(4096, dtype=torch.float32))
+        F, K, N, B = 129, 32, 40, 2
+        V = _problem(F, K, [N] * B, seed=5)
+        W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+        a, b = HipSharedNMF(V, W0, H0), HipSharedNMF(V, W0, H0)
+        a.run(5)
+        arr = (_hip.SharedShard * 1)()
+        arr[0].V, arr[0].H, arr[0].workspace, arr[0].N, arr[0].batch, arr[0].ld = _ptr(b.V), _ptr(b.Hd), _ptr(b.ws), N, B, 0
+        _hip.check(lib.gccnmf_klnmf_shared_run(arr, 1, _ptr(b.Wd), _ptr(b.partial), _ptr(b.vec), F, K, 5, 0.0, 1e-16,
+                                               lib.gccnmf_rccl_allreduce_hook(), comm, _stream()), 'gccnmf_klnmf_shared_run')
+        torch.cuda.synchronize()
+        assert np.array_equal(a.W(), b.W())
+    finally:
+        _hip.check(lib.gccnmf_rccl_comm_destroy(comm), 'gccnmf_rccl_comm_destroy')
 
 
 def test_rccl_single_rank_group():
@@ -126,11 +220,58 @@ def test_two_ranks_hip_shards_over_gloo_on_one_gpu(tmp_path):
     W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(2)]
     H = np.concatenate([np.load(tmp_path / ('H_rank%d.npy' % i)) for i in range(2)], axis=1)
     assert np.array_equal(W[0], W[1])
+    assert 'gloo' in open(tmp_path / 'collective_rank1.txt').read()          # the C loop called back into torch.distributed
     V = problem(F, [N] * B, 11)
     W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
     one = train_shared_dictionary(HipSharedNMF(V, W0, H0), iters)
     assert np.linalg.norm(W[0] - one.W()) < 1e-5 * np.linalg.norm(one.W())
     assert np.linalg.norm(H - np.concatenate(one.H(), axis=1)) < 1e-5 * np.linalg.norm(H)
+
+
+def _run_ranks(world, script, args, timeout=900):
+    import subprocess
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'tests', script)] + [str(a) for a in args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_eight_ranks_more_ranks_than_files(tmp_path):
+    """8-rank rehearsal on one GPU (gloo): 3 files -> ranks 3..7 hold no columns; every rank ends with the same W = the 1-rank W."""
+    import sys
+    from conftest import REPO
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from shared_rank_worker import problem
+    F, K, N, B, iters = 513, 256, 128, 3, 6
+    _run_ranks(8, 'shared_rank_worker.py', [tmp_path, F, K, N, B, iters])
+    W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(8)]
+    assert all(np.array_equal(W[0], w) for w in W[1:])
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    one = train_shared_dictionary(HipSharedNMF(problem(F, [N] * B, 11), W0, H0), iters)
+    assert np.linalg.norm(W[0] - one.W()) < 1e-5 * np.linalg.norm(one.W())
+
+
+def test_eight_ranks_at_config4_per_rank_shape(tmp_path):
+    """BASELINE config 4 rehearsed on one GPU: 8 ranks x 64 files of (513, 1244), K = 1024, per-file initialisation, the all-reduce of
+    541,696 floats per iteration over gloo; W identical on every rank and within 1e-5 (rel. Frobenius) of ONE rank holding all 512
+    files ('W parity vs single-GPU <= 1e-5')."""
+    import sys
+    from conftest import REPO
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from shared_rank_worker import problem
+    F, K, N, B, iters = 513, 1024, 1244, 512, 3
+    _run_ranks(8, 'shared_rank_worker.py', [tmp_path, F, K, N, B, iters, 'per_file'], timeout=1500)
+    W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(8)]
+    assert all(np.array_equal(W[0], w) for w in W[1:])
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='per_file')
+    one = train_shared_dictionary(HipSharedNMF(problem(F, [N] * B, 11), W0, H0), iters)
+    rel = np.linalg.norm(W[0] - one.W()) / np.linalg.norm(one.W())
+    print('config-4 shape, 8 ranks vs 1 rank: W rel. Frobenius %.2e' % rel)
+    assert rel < 1e-5
 
 
 def test_bench_launches_its_own_ranks():
@@ -144,12 +285,14 @@ def test_bench_launches_its_own_ranks():
     env['GCCNMF_BENCH_BACKEND'] = 'gloo'
     common = ['--files', '4', '--seconds', '2', '--iterations', '5', '--dictionary-size', '128', '--steps', '1', '--warmup', '0',
               '--skip-cpu-baseline', '--skip-roofline']
-    for mode in ('separate', 'shared-dictionary'):
-        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--mode', mode] + common, env=env,
-                           capture_output=True, text=True, timeout=600, cwd=REPO)
+    # 2 ranks, and the 8-rank rehearsal of the driver's scaling run (every mode; no flags beyond --gpus / --mode needed there)
+    for gpus, mode in ((2, 'separate'), (2, 'shared-dictionary'), (8, 'separate'), (8, 'shared-dictionary'), (8, 'time-sharded')):
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(gpus), '--mode', mode] + common, env=env,
+                           capture_output=True, text=True, timeout=900, cwd=REPO)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-        assert line['n_gpus'] == 2 and line['ranks_seen'] == 2, line
+        assert line['n_gpus'] == gpus and line['ranks_seen'] == gpus, line
+        assert np.isfinite(line['value']) and line['value'] > 0
     # a launcher environment that disagrees with --gpus is an error, not a warning
     env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2'] + common, env=env2, capture_output=True, text=True,

@@ -155,6 +155,104 @@ def test_stream_vs_reference_goldens(case):
     assert np.sqrt(sq / (2 * B * compared)) < 3e-5 * np.abs(x).max(), np.sqrt(sq / (2 * B * compared))
 
 
+@pytest.mark.parametrize('case', ['default', 'lowlatency', 'dev1'])
+def test_history_mirrors_vs_reference_stream_goldens(case):
+    """the host mirrors the reference GUI reads (gccNMFProcessor.py:211-229).  gccPHATHistory / tdoaHistory objects passed
+    to the constructor are filled after every block; after the whole stream they hold what the reference's own
+    SharedMemoryCircularBuffers held (goldens from the unmodified processor)."""
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF
+    g = np.load(os.path.join(GOLD, 'rt_stream_%s.npz' % case))
+    ws, hop, B, K, D, numBlocks, L, seed = [int(v) for v in g['params']]
+    W = R.make_rt_dictionary(seed, ws // 2 + 1, K)
+    Lh = g['gccPHATHistory'].shape[1]
+    gcc, tdoa = R.CircularHistory((D, Lh)), R.CircularHistory((1, Lh))
+    dev = GCCNMFProcessor(16000, ws, B // hop, {'Pretrained': {K: W}}, 'Pretrained', K, 0, float(g['d']), True, L, gccPHATHistory=gcc,
+                          tdoaHistory=tdoa, numTDOAs=D, numTDOAHistory=Lh)
+    dev.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    s = StreamingGCCNMF(dev, hop, B)
+    x = g['x']
+    for b in range(numBlocks):
+        s.process_block(x[:, b * B:(b + 1) * B])
+        if dev.targetTDOAIndex != g['tdoa'][b]:
+            assert g['loc_gap'][b] < NEAR_TIE
+            pytest.skip('the track left the reference at a genuine near-tie of its own localisation spectrum (block %d)' % b)
+    ref_t = g['tdoaHistory']
+    assert np.array_equal(tdoa.getUnraveledArray(), ref_t)                        # every block's tracked index, in ring order
+    got, ref = gcc.getUnraveledArray(), g['gccPHATHistory']
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.abs(got[ok] - ref[ok]).max() < 2e-4                                  # mean over F = 257..513 unit-modulus terms in float32
+
+
+def test_spectrogram_and_mask_history_mirrors():
+    """inputSpectrogramHistory / outputSpectrogramHistory / coefficientMaskHistories (gccNMFProcessor.py:211-217,228-229): the
+    reference's expressions, incl. -mean(|X|) ** (1/3.0) and 1 - coefficientMask, on the device's X, Y and HMask."""
+    from gcc_nmf_amd.realtime import GCCNMFProcessor
+    ws, K, D, Tc, Ls = 512, 96, 40, 4, 10
+    rng = np.random.RandomState(2)
+    W = R.make_rt_dictionary(5, ws // 2 + 1, K)
+    F = ws // 2 + 1
+    hin, hout, hmask = R.CircularHistory((F, Ls)), R.CircularHistory((F, Ls)), {K: R.CircularHistory((K, Ls))}
+    dev = GCCNMFProcessor(16000, ws, Tc, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, False, 6, inputSpectrogramHistory=hin,
+                          outputSpectrogramHistory=hout, coefficientMaskHistories=hmask, numTDOAs=D)
+    ora = R.GCCNMFProcessorOracle(16000, ws, Tc, W, 0.1, D, localizationEnabled=False)
+    for p in (dev, ora):
+        p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    for call in range(2):
+        frames = (rng.standard_normal((2, ws, Tc)) * 0.1).astype(np.float32)
+        dev.processFrames(frames)
+        ref, im = ora.processFrames(frames, return_intermediates=True)
+        cols = slice(call * Tc, (call + 1) * Tc)
+        want_in = -np.mean(np.abs(im['X']), axis=0) ** (1 / 3.0)
+        assert np.abs(hin.values[:, cols] - want_in).max() < 1e-5 * np.abs(want_in).max()
+        Y = im['tfMask'] * im['X']
+        want_out = -np.nanmean(np.abs(Y), axis=0) ** (1 / 3.0)
+        assert np.abs(hout.values[:, cols] - want_out).max() < 2e-3 * np.abs(want_out).max()       # soft mask through the arg-max
+        d = dev.intermediates()
+        assert np.array_equal(hmask[K].values[:, cols], (1 - d['HMask']).astype(np.float64))
+        assert np.abs(hmask[K].values[:, cols] - (1 - im['HMask'])).mean() < 1e-3
+    assert hin.index == 2 * Tc and hmask[K].index == 2 * Tc
+    # separation off: the output history mirrors the input spectrogram (:213-214), the mask history is not touched (:207-212)
+    dev.separationEnabled = False
+    dev.processFrames(frames)
+    assert np.array_equal(hout.values[:, 2 * Tc:3 * Tc], hin.values[:, 2 * Tc:3 * Tc]) and hmask[K].index == 2 * Tc
+
+
+def test_output_delay_must_cover_the_synthesis_window():
+    """outputDelayBlocks = 1 with the symmetric sqrt-hamming window would hand out partial overlap-add sums."""
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF, asymmetricWindows
+    ws, hop, K, D = 512, 64, 64, 32
+    W = R.make_rt_dictionary(2, ws // 2 + 1, K)
+    sym = GCCNMFProcessor(16000, ws, 1, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, False, 6, numTDOAs=D)
+    with pytest.raises(ValueError, match='before it is complete'):
+        StreamingGCCNMF(sym, hop, hop, outputDelayBlocks=1)
+    StreamingGCCNMF(sym, hop, hop, outputDelayBlocks=2)                       # the reference's own hand-out, pinned by the goldens
+    StreamingGCCNMF(sym, hop, hop, outputDelayBlocks=7)                       # 7 * 64 + 64 = 512: complete
+    a, sy = asymmetricWindows(ws, 2 * hop)
+    asym = GCCNMFProcessor(16000, ws, 1, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, False, 6, numTDOAs=D, analysisWindow=a, synthesisWindow=sy)
+    StreamingGCCNMF(asym, hop, hop, outputDelayBlocks=1)
+
+
+def test_reset_invalidates_the_captured_graph():
+    """reset() re-allocates every device buffer; the graph key carries the processor's generation, so a replay never
+    touches freed memory even if the allocator hands the old addresses out again."""
+    from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF
+    ws, hop, K, D = 512, 64, 64, 32
+    W = R.make_rt_dictionary(3, ws // 2 + 1, K)
+    x = O.synthetic_mixture(9, numSamples=40 * hop, delays=(-3, 1, 4))
+    p = GCCNMFProcessor(16000, ws, 1, {'Pretrained': {K: W}}, 'Pretrained', K, 0, 0.1, False, 6, numTDOAs=D)
+    s = StreamingGCCNMF(p, hop, hop)
+    first = [s.process_block(x[:, b * hop:(b + 1) * hop]) for b in range(20)]
+    key0 = s._graph_key
+    for _ in range(2):
+        p.reset()
+    s2 = StreamingGCCNMF(p, hop, hop)
+    s2._pin_in, s2._pin_out, s2._ev_out, s2._graph, s2._graph_key = s._pin_in, s._pin_out, s._ev_out, s._graph, s._graph_key
+    again = [s2.process_block(x[:, b * hop:(b + 1) * hop]) for b in range(20)]
+    assert s2._graph_key != key0 and s2.capture_error is None
+    assert all(np.array_equal(a, b) for a, b in zip(first, again))
+
+
 # ---- low-latency extensions (BASELINE config 5; no reference code exists for them: oracle "parity unpinned") --------------------
 @pytest.mark.parametrize('ws,K,D,Tc,n', [(512, 256, 64, 1, 1), (512, 1024, 64, 1, 3), (256, 96, 33, 4, 2)])
 def test_coefficient_inference_and_asymmetric_windows_match_oracle(ws, K, D, Tc, n):

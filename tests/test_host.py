@@ -16,7 +16,7 @@ HEADER = os.path.join(REPO, 'include', 'gccnmf_hip.h')
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|long)\s+(gccnmf_\w+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(?:int|long|gccnmf_allreduce_fn)\s+(gccnmf_\w+)\s*\(', src)))
 
 
 def test_library_exports_every_declared_symbol():
