@@ -292,7 +292,8 @@ def main():
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group(backend)
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     # every rank adds 1 over the data-path backend (RCCL unless GCCNMF_BENCH_BACKEND says otherwise): the job really is N ranks
     ranks_seen = 1

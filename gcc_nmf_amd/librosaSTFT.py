@@ -91,6 +91,20 @@ def _check_frames(y, n_fft, hop_length):
     return T
 
 
+def frame(y, frame_length=2048, hop_length=512):
+    """gccNMF/librosaSTFT.py:370-435: (frame_length, n_frames) strided VIEW of ``y`` with ``y_frames[i, j] == y[j * hop_length + i]``
+    (host utility, no copy; the device STFT reads the same overlapping frames straight from the sample buffer)."""
+    if hop_length < 1:
+        raise ParameterError('Invalid hop_length: {:d}'.format(hop_length))
+    if not y.flags['C_CONTIGUOUS']:
+        raise ParameterError('Input buffer must be contiguous.')
+    valid_audio(y)
+    n_frames = 1 + int((len(y) - frame_length) / hop_length)
+    if n_frames < 1:
+        raise ParameterError('Buffer is too short (n={:d}) for frame_length={:d}'.format(len(y), frame_length))
+    return np.lib.stride_tricks.as_strided(y, shape=(frame_length, n_frames), strides=(y.itemsize, hop_length * y.itemsize))
+
+
 def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
     """One packed complex FFT per frame carries both real signals (y1 may be None)."""
     _check_n_fft(n_fft)

@@ -24,7 +24,8 @@ def main(out_dir, F, K, N, B, iters, init='concat'):
     import torch
     import torch.distributed as dist
     from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, shard_files, train_shared_dictionary
-    dist.init_process_group('gloo')
+    import datetime
+    dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))      # a failed rank must not park the others for half an hour
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     mine = shard_files(B, world, rank)

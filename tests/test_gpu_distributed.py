@@ -228,7 +228,7 @@ def test_two_ranks_hip_shards_over_gloo_on_one_gpu(tmp_path):
     assert np.linalg.norm(H - np.concatenate(one.H(), axis=1)) < 1e-5 * np.linalg.norm(H)
 
 
-def _run_ranks(world, script, args, timeout=900):
+def _run_ranks(world, script, args, timeout=600):
     import subprocess
     import sys
     from conftest import REPO
@@ -264,7 +264,7 @@ def test_eight_ranks_at_config4_per_rank_shape(tmp_path):
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     from shared_rank_worker import problem
     F, K, N, B, iters = 513, 1024, 1244, 512, 3
-    _run_ranks(8, 'shared_rank_worker.py', [tmp_path, F, K, N, B, iters, 'per_file'], timeout=1500)
+    _run_ranks(8, 'shared_rank_worker.py', [tmp_path, F, K, N, B, iters, 'per_file'], timeout=900)
     W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(8)]
     assert all(np.array_equal(W[0], w) for w in W[1:])
     W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='per_file')

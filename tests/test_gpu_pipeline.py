@@ -13,6 +13,11 @@ torch = pytest.importorskip('torch')
 # (k, t) whose top-2 relative gap is below 1e-2 (conftest.mask_flips); a flip anywhere else fails.  The device's W/H differ from
 # the reference's by ~5e-6 relative after 100 iterations (summation order), so scores move by about that much: measured on
 # MI355X the largest gap that ever flipped is 5.6e-5 (dev1 in the six-file batch, K=1024; 0-6 flips per 637k coefficients), printed by the tests below (-s).
+# SURVEY 8(c) names 1e-5 (from 0 flips between an f32 and an f64 oracle run on dev1); that is below the reference's OWN noise floor:
+# the same NumPy/OpenBLAS float32 expressions with 1 vs 8 BLAS threads (sgemm summation order only; oracle/mask_noise_floor.py,
+# tests/golden/mask_noise_floor.json) differ by 1.6-2.1e-6 in W and flip 0-2 coefficients per mixture at K = 1024, the largest at a gap
+# of 3.9e-5 (dev_B).  The device's drift is 2-3x that thread-order noise (different k-tiling), hence 1e-4 = 2.6x the reference's own
+# largest self-flip; the kernels that divide V / (W.H) by rcp + Newton instead of IEEE change nothing here (scripts/mask_flips.py).
 TIE_LIMIT = 1e-4
 
 
@@ -80,7 +85,14 @@ def test_all_reference_mixtures_batched(K):
         ref = g['y'][:, :, ::8] if 'y' in g.files else g['y_sub']
         rms = np.sqrt(np.mean((y[i][:, :, ::8].astype(np.float64) - ref) ** 2))
         assert rms < 1e-5, (w, rms)      # bar 1e-4; measured <= 2.0e-6 (a near-tie flip moves one atom of one frame)
-        print('%s K=%d: mask flips %d (largest reference gap %.1e) waveform rms %.2e' % (w, K, flips, worst, rms))
+        wh = ''
+        if K == 1024:                    # the factors of EVERY reference mixture against the reference's own (oracle/make_golden_wh.py)
+            gw = golden('wh_sub_K1024')
+            W, H = e.get_WH()
+            rw, rh = rel(W[i][:, ::16], gw[w + '_W']), rel(H[i][::16, ::2], gw[w + '_H'])
+            assert rw < 1e-4 and rh < 1e-4, (w, rw, rh)      # SURVEY 8(c) bar; the reference against itself (1 vs 8 BLAS threads): 2e-6
+            wh = ' W rel %.2e H rel %.2e' % (rw, rh)
+        print('%s K=%d: mask flips %d (largest reference gap %.1e) waveform rms %.2e%s' % (w, K, flips, worst, rms, wh))
 
 
 @pytest.mark.parametrize('K', [128, 1024])

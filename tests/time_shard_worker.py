@@ -14,7 +14,8 @@ def main(out_dir, n, K, iters):
     import torch.distributed as dist
     from gcc_nmf_amd.distributed import HipTimeShard, separate_time_sharded
     from gcc_nmf_amd.synthetic import synthetic_mixture
-    dist.init_process_group('gloo')
+    import datetime
+    dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))      # a failed rank must not park the others for half an hour
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     x = synthetic_mixture(11, numSamples=n)
