@@ -33,6 +33,9 @@ SIGNATURES = {
     'gccnmf_pitches': (c_int, [c_int, c_int, c_int, P_INT, P_INT, P_INT, P_INT]),
     'gccnmf_stft_stereo': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_dft_workspace_floats': (c_long, [c_int, c_int, c_int]),
+    'gccnmf_stft_dft': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'gccnmf_istft_dft': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     'gccnmf_stft_stereo_pcm16': (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     'gccnmf_pack_pcm16': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

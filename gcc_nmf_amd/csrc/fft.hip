@@ -439,3 +439,93 @@ int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scra
 }
 
 }  // extern "C"
+
+// ---- any n_fft: the DFT as a real GEMM on the matrix cores -------------------------------------------------------------------------
+// The reference's stft / istft take ANY n_fft (scipy.fftpack, librosaSTFT.py:162-179, :276-279); the radix-2 kernels above take powers of
+// two.  Other sizes are rare (off the GCC-NMF path's defaults) and small, so they do not get a mixed-radix FFT: the transform is the
+// matrix product it is, on v_mfma_f32_32x32x2_f32 (exact-f32 fmaf chains) through the same GEMM kernels as the rest of the path --
+//   forward:  [Re X; Im X] (2Fp x T) = basis^T (2Fp x N) . frames (N x T),   basis[n][f] = w[n] cos(2 pi f n / N), [n][Fp+f] = w[n] sin(..)
+//             (the reference stores conj(fft): Im X = + sum w y sin)
+//   inverse:  frames (T x N) = [Re S; Im S]^T (T x 2Fp) . ibasis (2Fp x N),  ibasis[k][n] = c_k w[n] cos(2 pi k n / N) / N, [Fp+k][n] = c_k w[n] sin(..) / N
+//             with c_0 = c_{N/2} = 1, c_k = 2 otherwise: the real part of ifft([conj(S), S[-2:0:-1]]) (librosaSTFT.py:277-279)
+// Both tables are evaluated in float64 on the host (like the twiddles).  2 N F flop per frame and signal: N = 1000 -> 1 MFLOP.
+int gccnmf_gemm_nn_store(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc, int batch, long sA,
+                         long sB, long sC, hipStream_t s);        // gcc.hip: C = A^T-layout . B, both operands [reduction][.]
+
+// framesT[sig][n][t] = x[sig][t*hop + n]   (grid = (ceil(Tp/256), N, nsig); rows n >= N and columns t >= T are never written: zero)
+__global__ __launch_bounds__(256) void dft_frames_kernel(const float* __restrict__ x, long x_stride, int N, int Np16, int hop, int T, int Tp,
+                                                         float* __restrict__ framesT) {
+    const int t = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (t >= T) return;
+    framesT[((long)blockIdx.z * Np16 + n) * Tp + t] = x[blockIdx.z * x_stride + (long)t * hop + n];
+}
+
+// planes[sig][2Fp][Tp] -> X[sig][Fp][Tp] interleaved complex (valid F x T region only)
+__global__ __launch_bounds__(256) void dft_pack_kernel(const float* __restrict__ planes, int F, int Fp, int T, int Tp, float2* __restrict__ X) {
+    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (t >= T) return;
+    const float* P = planes + (long)blockIdx.z * 2 * Fp * Tp;
+    X[((long)blockIdx.z * Fp + f) * Tp + t] = make_float2(P[(long)f * Tp + t], P[(long)(Fp + f) * Tp + t]);
+}
+
+// spec[sig][Fp][Tp] complex -> planes[sig][2Fp][Tp]
+__global__ __launch_bounds__(256) void dft_unpack_kernel(const float2* __restrict__ spec, int F, int Fp, int T, int Tp, float* __restrict__ planes) {
+    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (t >= T) return;
+    const float2 v = spec[((long)blockIdx.z * Fp + f) * Tp + t];
+    float* P = planes + (long)blockIdx.z * 2 * Fp * Tp;
+    P[(long)f * Tp + t] = v.x;
+    P[(long)(Fp + f) * Tp + t] = v.y;
+}
+
+extern "C" {
+
+long gccnmf_dft_workspace_floats(int n_fft, int T, int nsig) {
+    if (n_fft < 2 || T < 1 || nsig < 1) return -1;
+    GccNmfPitches p = gccnmf_make_pitches(n_fft / 2 + 1, T, 1);
+    const long fwd = (long)nsig * ((long)gccnmf_round_up(n_fft, 16) + 2L * p.Fp) * p.Tp;      // framesT | planes
+    const long inv = (long)nsig * (2L * p.Fp * p.Tp + (long)T * n_fft);                         // planes | frames
+    return fwd > inv ? fwd : inv;
+}
+
+int gccnmf_stft_dft(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int nsig, const float* basis,
+                    float* workspace, float* X, void* stream) {
+    if (!x || !basis || !workspace || !X || n_fft < 2 || n_fft > 8192 || hop < 1 || T < 1 || nsig < 1) return GCCNMF_ERR_ARG;
+    if ((long)(T - 1) * hop + n_fft > n_samples) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int F = n_fft / 2 + 1, Np16 = gccnmf_round_up(n_fft, 16);
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    float* framesT = workspace;
+    float* planes = framesT + (long)nsig * Np16 * p.Tp;
+    if (hipMemsetAsync(framesT, 0, sizeof(float) * nsig * Np16 * p.Tp, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(dft_frames_kernel, dim3(gccnmf_ceil_div(T, 256), n_fft, nsig), dim3(256), 0, s, x, x_stride, n_fft, Np16, hop, T, p.Tp, framesT);
+    GCCNMF_CHECK_LAUNCH();
+    int rc = gccnmf_gemm_nn_store(basis, framesT, planes, 2 * p.Fp, T, n_fft, 2 * p.Fp, p.Tp, p.Tp, nsig, 0L, (long)Np16 * p.Tp, 2L * p.Fp * p.Tp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dft_pack_kernel, dim3(gccnmf_ceil_div(T, 256), F, nsig), dim3(256), 0, s, planes, F, p.Fp, T, p.Tp, (float2*)X);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_istft_dft(const float* spec, int nsig, int n_fft, int hop, int T, const float* ibasis, float gain, int center, float* workspace,
+                     float* y, void* stream) {
+    if (!spec || !ibasis || !workspace || !y || n_fft < 2 || n_fft > 8192 || (n_fft & 1) || hop < 1 || T < 1 || nsig < 1) return GCCNMF_ERR_ARG;
+    const int trim = center ? n_fft / 2 : 0;
+    const int L = n_fft + hop * (T - 1) - 2 * trim;
+    if (L < 1) return GCCNMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int F = n_fft / 2 + 1, Nb = gccnmf_round_up(n_fft, 64);
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    float* planes = workspace;
+    float* frames = planes + (long)nsig * 2 * p.Fp * p.Tp;
+    if (hipMemsetAsync(planes, 0, sizeof(float) * nsig * 2 * p.Fp * p.Tp, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    hipLaunchKernelGGL(dft_unpack_kernel, dim3(gccnmf_ceil_div(T, 256), F, nsig), dim3(256), 0, s, (const float2*)spec, F, p.Fp, T, p.Tp, planes);
+    GCCNMF_CHECK_LAUNCH();
+    int rc = gccnmf_gemm_nn_store(planes, ibasis, frames, T, n_fft, 2 * p.Fp, p.Tp, Nb, n_fft, nsig, 2L * p.Fp * p.Tp, 0L, (long)T * n_fft, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(gccnmf_ceil_div(L, 256), nsig, 1), dim3(256), 0, s, frames, n_fft, hop, T, L, trim, gain, y);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+}  // extern "C"

@@ -186,6 +186,21 @@ __global__ __launch_bounds__(256) void gcc_masked_h_kernel(const float* __restri
     Hm[((long)b * Kp + k) * (long)ncol + col] = out;
 }
 
+// C [batch][M][ldc] = A . B with both operands stored [reduction][.] (A(i,kk) = A[kk*lda + i], B(kk,j) = B[kk*ldb + j]), plain store:
+// the DFT-as-GEMM path of fft.hip (any n_fft).  Rows of A / B between Kd and the next multiple of 16 must exist and be zero;
+// lda, ldb multiples of 4 and >= the tile overreach (operands padded to multiples of 64 columns).
+int gccnmf_gemm_nn_store(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc, int batch, long sA,
+                         long sB, long sC, hipStream_t s) {
+    GemmArgs a = {};
+    a.A = A; a.sA = sA; a.lda = lda; a.a_clamp = lda - 4;
+    a.B = B; a.sB = sB; a.ldb = ldb; a.b_clamp = ldb - 4;
+    a.M = M; a.N = N; a.Kd = Kd;
+    a.batch = batch; a.xcd_affine = 0;
+    a.C = C; a.sC = sC; a.ldc = ldc;
+    if (gcc_small_launch(batch, a.M, a.N, a.Kd)) return gccnmf_launch_gemm_ring<false, false, EPI_STORE, false>(a, s);
+    return (M > 128) ? gccnmf_launch_gemm<4, 1, false, false, EPI_STORE, false>(a, s) : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
+}
+
 extern "C" {
 
 int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T, int D, int batch, float* ang,

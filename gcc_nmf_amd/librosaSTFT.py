@@ -62,14 +62,40 @@ def _window_vector(window, win_length, n_fft, inverse=False):
     return pad_center(w, n_fft)
 
 
-SUPPORTED_N_FFT = (64, 128, 256, 512, 1024, 2048, 4096)
+RADIX2_N_FFT = (64, 128, 256, 512, 1024, 2048, 4096)     # the LDS radix-2 kernels (csrc/fft.hip); every other size: DFT as a GEMM on the matrix cores
+MAX_N_FFT = 8192
 
 
 def _check_n_fft(n_fft):
-    """The device FFT is a radix-2 kernel that keeps eight (n_fft = 4096: four) frames of one workgroup in LDS: powers of two from 64
-    to 4096 (the reference accepts any n_fft)."""
-    if int(n_fft) not in SUPPORTED_N_FFT:
-        raise ParameterError('n_fft={} is not supported by the HIP STFT/iSTFT: use one of {}'.format(n_fft, SUPPORTED_N_FFT))
+    """Like the reference, any n_fft: powers of two from 64 to 4096 run the radix-2 kernels, every other size up to 8192 the
+    DFT-as-GEMM path (gccnmf_stft_dft / gccnmf_istft_dft)."""
+    if not 2 <= int(n_fft) <= MAX_N_FFT:
+        raise ParameterError('n_fft={} is not supported by the HIP STFT/iSTFT: 2 .. {}'.format(n_fft, MAX_N_FFT))
+
+
+def dft_basis(window, n_fft, Fp):
+    """[round_up(n_fft,16)][2*Fp] float32: w[n] cos / sin(2 pi f n / n_fft), float64 on the host (librosaSTFT.py:176-179 transforms in
+    float64 too)."""
+    F = n_fft // 2 + 1
+    ang = 2.0 * np.pi * np.outer(np.arange(n_fft, dtype=np.float64), np.arange(F, dtype=np.float64)) / n_fft
+    w = np.asarray(window, np.float64)[:, None]
+    b = np.zeros((-(-n_fft // 16) * 16, 2 * Fp), np.float32)
+    b[:n_fft, :F] = w * np.cos(ang)
+    b[:n_fft, Fp:Fp + F] = w * np.sin(ang)
+    return b
+
+
+def idft_basis(window, n_fft, Fp):
+    """[2*Fp][round_up(n_fft,64)] float32: c_k w[n] cos / sin(2 pi k n / n_fft) / n_fft with c_0 = c_{n_fft/2} = 1, else 2."""
+    F = n_fft // 2 + 1
+    ang = 2.0 * np.pi * np.outer(np.arange(F, dtype=np.float64), np.arange(n_fft, dtype=np.float64)) / n_fft
+    c = np.full((F, 1), 2.0)
+    c[0] = c[F - 1] = 1.0
+    w = np.asarray(window, np.float64)[None, :]
+    b = np.zeros((2 * Fp, -(-n_fft // 64) * 64), np.float32)
+    b[:F, :n_fft] = c * w * np.cos(ang) / n_fft
+    b[Fp:Fp + F, :n_fft] = c * w * np.sin(ang) / n_fft
+    return b
 
 
 def _device():
@@ -130,6 +156,13 @@ def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
     x = torch.zeros((2, n), dtype=torch.float32, device=dev)
     for c, y in enumerate(chans):
         x[c] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
+    if int(n_fft) not in RADIX2_N_FFT:
+        basis = torch.from_numpy(dft_basis(w, n_fft, g.Fp)).to(dev)
+        ws = torch.zeros(lib.gccnmf_dft_workspace_floats(n_fft, T, 2), dtype=torch.float32, device=dev)
+        X = torch.zeros((2, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
+        _hip.check(lib.gccnmf_stft_dft(_ptr(x), n, n, n_fft, hop_length, T, 2, _ptr(basis), _ptr(ws), _ptr(X), _stream()), 'gccnmf_stft_dft')
+        out = torch.view_as_complex(X)[:, :F, :T].cpu().numpy()
+        return out if y1 is not None else out[0]
     dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
     dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
     X = torch.zeros((2, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
@@ -160,6 +193,16 @@ def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
     npad = nsig + (nsig & 1)
     host = np.ascontiguousarray(specs.astype(np.complex64)).view(np.float32).reshape(nsig, F, T, 2)
     dS = padded(host, (npad, g.Fp, g.Tp, 2), dev)
+    if int(n_fft) not in RADIX2_N_FFT:
+        L = n_fft + hop_length * (T - 1) - (n_fft if center else 0)
+        if L < 1:
+            return np.zeros((nsig, 0), np.float32)
+        ibasis = torch.from_numpy(idft_basis(w, n_fft, g.Fp)).to(dev)
+        ws = torch.zeros(lib.gccnmf_dft_workspace_floats(n_fft, T, npad), dtype=torch.float32, device=dev)
+        y = torch.zeros((npad, L), dtype=torch.float32, device=dev)
+        _hip.check(lib.gccnmf_istft_dft(_ptr(dS), npad, n_fft, hop_length, T, _ptr(ibasis), np.float32(gain), 1 if center else 0, _ptr(ws),
+                                        _ptr(y), _stream()), 'gccnmf_istft_dft')
+        return y[:nsig].cpu().numpy()
     dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
     dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
     frames = torch.zeros((npad, T, n_fft), dtype=torch.float32, device=dev)

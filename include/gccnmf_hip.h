@@ -64,11 +64,25 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp);
  *   window   [n_fft] float32 analysis window (numpy.hanning(n_fft) for the reference path)
  *   twiddle  [n_fft/2] complex: exp(-2j*pi*k/n_fft), computed in float64 on the host
  *   X, V, CC as in the geometry table; V or CC may be NULL to skip that output.
- * LIMITS (the reference accepts any size): n_fft must be a power of two in [64, 4096] -- the radix-2 kernel keeps eight
- * frames per workgroup in LDS (four at n_fft = 4096); other sizes GCCNMF_ERR_ARG.  The same holds for gccnmf_istft_ola.
- * The Python layer raises ParameterError naming the sizes. */
+ * n_fft must be a power of two in [64, 4096] here -- the radix-2 kernel keeps eight frames per workgroup in LDS (four at
+ * n_fft = 4096); other sizes GCCNMF_ERR_ARG.  The same holds for gccnmf_istft_ola.  Every other size goes through
+ * gccnmf_stft_dft / gccnmf_istft_dft below (the Python stft / istft choose). */
 int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch,
                        const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream);
+
+/* ANY n_fft (2..8192, e.g. 400, 1000, 1536): the reference's stft / istft accept every size (scipy.fftpack, librosaSTFT.py:162-179,
+ * :276-279).  Off the power-of-two sizes the transform is computed as the real GEMM it is, on the matrix cores (csrc/fft.hip):
+ *   gccnmf_stft_dft : x [nsig][n_samples] real signals (x_stride floats apart) -> X [nsig][Fp][Tp] complex (= conj(fft), center=False)
+ *     basis [round_up(n_fft,16)][2*Fp]: basis[n][f] = w[n] cos(2 pi f n / n_fft), basis[n][Fp+f] = w[n] sin(..), zero elsewhere
+ *   gccnmf_istft_dft: spec [nsig][Fp][Tp] complex -> y [nsig][L], L = n_fft + hop*(T-1) - (center ? n_fft : 0); n_fft even
+ *     ibasis [2*Fp][round_up(n_fft,64)]: ibasis[k][n] = c_k w[n] cos(2 pi k n / n_fft) / n_fft, ibasis[Fp+k][n] = c_k w[n] sin(..) / n_fft,
+ *     c_0 = c_{n_fft/2} = 1, else 2 (the real part of ifft([conj(S), S[-2:0:-1]]) times the synthesis window)
+ *   both tables are evaluated in float64 by the caller; workspace: gccnmf_dft_workspace_floats(n_fft, T, nsig) floats. */
+long gccnmf_dft_workspace_floats(int n_fft, int T, int nsig);
+int gccnmf_stft_dft(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int nsig, const float* basis,
+                    float* workspace, float* X, void* stream);
+int gccnmf_istft_dft(const float* spec, int nsig, int n_fft, int hop, int T, const float* ibasis, float gain, int center, float* workspace,
+                     float* y, void* stream);
 
 /* The same with the wav ingest fused in: pcm = interleaved int16 stereo frames [batch][n_samples][2]
  * exactly as they sit in a wav data chunk (frame_stride stereo frames between files); the /32768 conversion of

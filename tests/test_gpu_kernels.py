@@ -137,6 +137,38 @@ def test_istft_n_fft_4096(hip):
     assert np.abs(stft(sig.copy(), 4096, 1024, 4096, np.hanning, center=True) - S).max() < 1e-5 * np.abs(S).max()
 
 
+@pytest.mark.parametrize('key', ['400_100', '1000_250', '1536_384', '1000_300'])
+def test_any_n_fft_against_the_reference(hip, key):
+    """Non-power-of-two n_fft (the reference takes any size, librosaSTFT.py:162-179): the DFT-as-GEMM path against outputs of the
+    UNMODIFIED reference stft / istft (tests/golden/kat_nfft.npz, oracle/make_golden_wh.py)."""
+    from gcc_nmf_amd.librosaSTFT import stft, istft
+    kat = golden('kat_nfft')
+    n_fft, hop = [int(v) for v in key.split('_')]
+    y, S, yi, yc = kat['y_' + key], kat['S_' + key], kat['yi_' + key], kat['yc_' + key]
+    X = stft(y.copy(), n_fft, hop, n_fft, np.hanning, center=False)
+    assert X.shape == S.shape and X.dtype == np.complex64 and X.flags['F_CONTIGUOUS']
+    assert np.abs(X - S).max() < 1e-5 * np.abs(S).max()
+    got = istft(S, hop, n_fft, np.hanning)
+    assert got.shape == yi.shape and got.dtype == np.float32 and np.abs(got - yi).max() < 1e-5 * np.abs(yi).max()
+    got = istft(S, hop, n_fft, np.hanning, center=False)
+    assert got.shape == yc.shape and np.abs(got - yc).max() < 1e-5 * np.abs(yc).max()
+
+
+def test_odd_and_tiny_n_fft_against_the_oracle(hip):
+    from gcc_nmf_amd.librosaSTFT import stft
+    from gcc_nmf_amd import gccNMFFunctions as G
+    rng = np.random.RandomState(12)
+    y = (rng.standard_normal(5000) * 0.1).astype(np.float32)
+    for n_fft, hop in [(375, 125), (30, 7), (2049, 512), (48, 48)]:
+        X = stft(y, n_fft, hop, n_fft, np.hanning, center=False)
+        ref = O.stft(y, n_fft, hop, n_fft, np.hanning, center=False)
+        assert X.shape == ref.shape and np.abs(X - ref).max() < 1e-5 * np.abs(ref).max(), n_fft
+    x2 = (rng.standard_normal((2, 9000)) * 0.1).astype(np.float32)
+    X = G.computeComplexMixtureSpectrogram(x2, 1000, 250, np.hanning)              # both channels through one GEMM launch
+    ref = O.computeComplexMixtureSpectrogram(x2, 1000, 250, np.hanning)
+    assert X.shape == ref.shape == (2, 501, 33) and np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 def test_stft_mono_center_and_errors(hip):
     from gcc_nmf_amd.librosaSTFT import stft, istft, ParameterError
     rng = np.random.RandomState(3)

@@ -165,11 +165,37 @@ def test_bench_contract_defaults_and_loud_failure_without_gpu(monkeypatch):
             GCCNMFEngine(160000, dictionarySize=1024, batch=1)
 
 
-def test_unsupported_fft_sizes_are_named():
-    """The reference accepts any n_fft; the HIP FFT supports powers of two from 64 to 4096 and says so."""
+def test_fft_size_limits_are_named():
+    """Like the reference, any n_fft is taken (powers of two: radix-2 kernels; other sizes: DFT as a GEMM); the limits are 2..8192."""
     from gcc_nmf_amd import librosaSTFT as L
-    for n_fft in (8192, 1000, 32):
+    for n_fft in (16384, 1, 8193):
         with pytest.raises(L.ParameterError, match='not supported'):
-            L.stft(np.zeros(20000, np.float32), n_fft=n_fft, hop_length=256, window=np.hanning, center=False)
+            L.stft(np.zeros(40000, np.float32), n_fft=n_fft, hop_length=256, window=np.hanning, center=False)
     with pytest.raises(L.ParameterError, match='not supported'):
-        L.istft(np.zeros((4097, 4), np.complex64), hop_length=256, window=np.hanning)
+        L.istft(np.zeros((8194, 4), np.complex64), hop_length=256, window=np.hanning)
+
+
+def test_frame_is_the_reference_strided_view():
+    """gccNMF/librosaSTFT.py:370-435: y_frames[i, j] == y[j * hop + i], a view, tail samples dropped, same errors."""
+    from gcc_nmf_amd import librosaSTFT as L
+    y = np.arange(1000, dtype=np.float32)
+    f = L.frame(y, frame_length=256, hop_length=100)
+    assert f.shape == (256, 1 + (1000 - 256) // 100) and f[7, 3] == y[3 * 100 + 7] and np.shares_memory(f, y)
+    assert np.array_equal(f[:, -1], y[700:956])
+    with pytest.raises(L.ParameterError, match='Invalid hop_length'):
+        L.frame(y, 256, 0)
+    with pytest.raises(L.ParameterError, match='contiguous'):
+        L.frame(y[::2], 256, 100)
+    with pytest.raises(L.ParameterError, match='too short'):
+        L.frame(y[:100], 256, 100)
+    # the DFT-as-GEMM tables of the any-n_fft path: shapes, and that they ARE the transform (float64 reference on the host)
+    w, n_fft, Fp = np.hanning(10), 10, 16
+    b, ib = L.dft_basis(w, n_fft, Fp), L.idft_basis(w, n_fft, Fp)
+    assert b.shape == (16, 32) and ib.shape == (32, 64)
+    x = np.random.RandomState(0).standard_normal(n_fft)
+    X = np.conj(np.fft.rfft(w * x))
+    assert np.allclose(x @ b[:n_fft, :6].astype(np.float64), X.real, atol=1e-6) and np.allclose(x @ b[:n_fft, Fp:Fp + 6].astype(np.float64), X.imag, atol=1e-6)
+    full = np.concatenate([X.conj(), X[-2:0:-1]])
+    want = w * np.fft.ifft(full).real
+    got = X.real @ ib[:6, :n_fft].astype(np.float64) + X.imag @ ib[Fp:Fp + 6, :n_fft].astype(np.float64)
+    assert np.allclose(got, want, atol=1e-6)
