@@ -46,6 +46,7 @@ def parse():
                         'whole batch, the configuration the roofline kernel is timed in')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
+    p.add_argument('--skip-extras', action='store_true', help='sweeps: only the timed steps and the roofline kernel (no host-to-host, single-file, drop-in, CPU legs)')
     p.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='gccnmf_set_tuning(KEY, VALUE) before running (A/B experiments)')
     p.add_argument('--h-updates', type=int, default=2, help='streaming mode: KL-NMF coefficient updates per frame (W fixed)')
     p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming', 'time-sharded'], default='separate',
@@ -375,13 +376,15 @@ def main():
     out['end_to_end_vs_mfma_roofline'] = {'flop_per_frame': flop_per_frame, 'ceiling_frames_per_s_per_gpu': ceiling,
                                           'frac': frames / elapsed / world / ceiling}
 
-    if rank == 0:
+    if rank == 0 and not a.skip_extras:
         # host float32 samples in -> host float32 waveforms out (PCIe both ways); reported beside `value`, never as `value`
         e.separate(xs)                                           # allocates the page-locked staging buffers (slow, once per engine)
         t1 = time.perf_counter()
         e.separate(xs)
         out['host_to_host_frames_per_s'] = B * g.T / (time.perf_counter() - t1)           # one batch, copies not overlapped
         nb = 8                                                   # fill + drain of the pipeline are ~1/3 of a batch time: amortised over 8
+        for _y in e.separate_batches([xs]):                      # allocates the second device slot + the pipeline's page-locked buffers
+            pass
         t1 = time.perf_counter()
         for _y in e.separate_batches(xs for _ in range(nb)):
             pass
@@ -394,10 +397,10 @@ def main():
                                              'i+-1 under the compute of batch i), pipeline fill and drain included' % (nb, B),
                                      'single_batch_unpipelined': out['host_to_host_frames_per_s'],
                                      'hbm_resident': frames / elapsed / world}
-        traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
-        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
 
     if rank == 0 and not a.skip_roofline:
+        traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
         iter_ms, k3_ms = kernel_timings(e)
         flop_per_launch = 2.0 * g.F * g.K * g.N * B                          # algorithmic: F=513, N=2T, not the padded tile grid
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
@@ -417,7 +420,7 @@ def main():
         out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12,
                                            'frac_of_peak': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.skip_extras:
         # the same parameters on ONE mixture (BASELINE config 2's shape): latency-bound, small-batch GEMM tile
         e1 = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=a.hop, numTDOAs=128, microphoneSeparationInMetres=1.0,
                           numTargets=3, dictionarySize=K, numIterations=iters, batch=1, device='cuda:%d' % local_rank)
@@ -433,7 +436,7 @@ def main():
                               # different GEMM tile (launch-size dependent) -> different summation grouping, not bitwise equal
                               'waveform_rms_vs_in_batch': float(np.sqrt(np.mean((e1.y[0].cpu().numpy().astype(np.float64) - e.y[0].cpu().numpy()) ** 2)))}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.skip_extras:
         # the drop-in route: the reference-named host-array function (NumPy V in -> NumPy W, H out), as runGCCNMF.py calls it
         from gcc_nmf_amd import gccNMFFunctions as G
         V0 = e.get_V()[0]
@@ -444,7 +447,7 @@ def main():
                                       'what': 'gcc_nmf_amd.gccNMFFunctions.performKLNMF(V (%d, %d) ndarray, %d, %d, 0): host arrays in and out'
                                               % (g.F, g.N, K, iters)}
 
-    if rank == 0 and world == 1 and not a.skip_cpu_baseline:
+    if rank == 0 and world == 1 and not a.skip_cpu_baseline and not a.skip_extras:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline
         from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])

@@ -74,6 +74,7 @@ SIGNATURES = {
     'gccnmf_istft_ola': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
                                  c_void_p, c_void_p, c_void_p]),
     'gccnmf_ola_frames': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'gccnmf_ola_frames_halo': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'gccnmf_rt_process_block': (c_int, [c_void_p] * 19 + [c_int] * 13 + [c_void_p]),
     'gccnmf_rt_process_block_ll': (c_int, [c_void_p] * 23 + [c_int] * 15 + [c_void_p]),
     'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),

@@ -147,19 +147,23 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
 // Overlap-add in ASCENDING frame order (the order librosaSTFT.py:275-281 accumulates in), centre trim
 // of `trim` samples at both ends (:283-284), times the gain (gccNMFFunctions.py:155,163).
 // grid = (ceil(L/256), nsig, batch).
+// halo > 0: the frame sequence of a signal is `halo` frames from `prev` ([sig][halo][N], e.g. the previous time shard's last frames)
+// followed by the T - halo frames of `frames` ([sig][T - halo][N]).
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, int N, int hop, int T, int L, int trim,
-                                                        float gain, float* __restrict__ y) {
+                                                        float gain, float* __restrict__ y, const float* __restrict__ prev = nullptr,
+                                                        int halo = 0) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= L) return;
     const long sig = (long)blockIdx.z * gridDim.y + blockIdx.y;
-    const float* fr = frames + sig * (long)T * N;
+    const float* fr = frames + sig * (long)(T - halo) * N;
+    const float* pv = prev + sig * (long)halo * N;
     const int s = m + trim;
     int t_lo = (s - N + hop) / hop;       // ceil((s - N + 1) / hop) for s - N + 1 > 0
     if (s - N + 1 <= 0) t_lo = 0;
     int t_hi = s / hop;
     if (t_hi > T - 1) t_hi = T - 1;
     float acc = 0.f;
-    for (int t = t_lo; t <= t_hi; ++t) acc = acc + fr[(long)t * N + (s - t * hop)];
+    for (int t = t_lo; t <= t_hi; ++t) acc = acc + (t < halo ? pv[(long)t * N + (s - t * hop)] : fr[(long)(t - halo) * N + (s - t * hop)]);
     y[sig * L + m] = acc * gain;
 }
 
@@ -422,7 +426,18 @@ int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, 
         (long)first_sample + L > (long)n_fft + (long)hop * (T - 1))
         return GCCNMF_ERR_ARG;
     hipLaunchKernelGGL(istft_ola_kernel, dim3(gccnmf_ceil_div(L, 256), nsig, batch), dim3(256), 0, (hipStream_t)stream, frames, n_fft, hop, T,
-                       L, first_sample, gain, y);
+                       L, first_sample, gain, y, (const float*)nullptr, 0);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int nsig, int n_fft, int hop, int T, int first_sample, int L,
+                           float gain, float* y, void* stream) {
+    if (!frames || !y || nsig < 1 || n_fft < 2 || hop < 1 || T < 1 || halo < 0 || (halo > 0 && !prev) || first_sample < 0 || L < 1 ||
+        (long)first_sample + L > (long)n_fft + (long)hop * (halo + T - 1))
+        return GCCNMF_ERR_ARG;
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(gccnmf_ceil_div(L, 256), nsig, 1), dim3(256), 0, (hipStream_t)stream, frames, n_fft, hop, halo + T,
+                       L, first_sample, gain, y, prev, halo);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

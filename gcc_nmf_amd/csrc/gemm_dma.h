@@ -379,10 +379,14 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const int tiles = p.tiles_m * p.tiles_n;
     int file, tile;
     if (p.xcd_affine) {
+        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the file-major tile list (chunk = xcd_affine = ceil(total / 8)):
+        // balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles on XCD 0 and 3 on the others), and a file
+        // still sits on one XCD (or straddles two neighbours)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        file = xcd + 8 * (slot / tiles);
-        tile = slot % tiles;
-        if (file >= p.batch) return;
+        const int idx = xcd * p.xcd_affine + slot;
+        if (idx >= p.batch * tiles) return;
+        file = idx / tiles;
+        tile = idx - file * tiles;
     } else {
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
@@ -817,8 +821,8 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     const int tiles = a.tiles_m * a.tiles_n;
     int grid;
     if (a.xcd_affine && a.batch >= 8) {
-        a.xcd_affine = 1;
-        grid = 8 * gccnmf_ceil_div(a.batch, 8) * tiles;
+        a.xcd_affine = gccnmf_ceil_div(a.batch * tiles, 8);     // tiles per XCD
+        grid = 8 * a.xcd_affine;
     } else {
         a.xcd_affine = 0;
         grid = a.batch * tiles;

@@ -10,10 +10,13 @@
 // The compensating rescale H *= norms (:81) is NOT a separate pass over H: it is the vector s,
 // applied while K1 stages its B operand and inside K2's epilogue (which rewrites H anyway).
 // gccnmf_klnmf materialises it once after the last iteration.
+#include <mutex>
 #include "gemm_ring.h"
 #include "../../include/gccnmf_hip.h"
 
 int gccnmf_tune_ablate = 0;
+#define GCCNMF_SHARED_STREAMS 4
+int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
 int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
@@ -41,6 +44,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 4) {
         gccnmf_tune_ring = value ? 1 : 0;
+        return GCCNMF_OK;
+    }
+    if (key == 8 && value >= 1 && value <= GCCNMF_SHARED_STREAMS) {
+        gccnmf_tune_shared_groups = value;
         return GCCNMF_OK;
     }
     if (key == 7 && (value == 0 || value == 1)) {
@@ -699,9 +706,48 @@ static int shared_begin(const SharedShard* sh, int n, const float* W, float* col
     return GCCNMF_OK;
 }
 
-// H update with the current W, then partial (+)= [sum_files (V/WH).H^T || sum_files rowsum H]
-static int shared_step_a(const SharedShard& sh, const float* W, const float* colsumW, const float* hscale, float* partial,
-                         int accumulate, float alpha, float eps, hipStream_t s) {
+// Side streams of the shared-dictionary iteration.  K1 .. K4a of different files (column blocks) are independent until the W update,
+// so a rank's files run as up to GCCNMF_SHARED_STREAMS groups on separate streams (tuning key 8, default 2): the tail of one group's
+// launch -- when its last workgroups no longer fill both slots of every CU -- overlaps the head of another group's, exactly as the
+// per-file-dictionary engine does with its file groups.  Same kernels on the same data: bitwise the one-stream result.
+struct SidePool {
+    hipStream_t side[GCCNMF_SHARED_STREAMS - 1];
+    hipEvent_t fork, join[GCCNMF_SHARED_STREAMS - 1];
+    bool ok = false;
+};
+static SidePool* side_pool() {
+    static SidePool pools[GCCNMF_MAX_DEVICES];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GCCNMF_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SidePool& p = pools[dev];
+    if (!p.ok) {
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        for (int i = 0; i < GCCNMF_SHARED_STREAMS - 1; ++i) {
+            if (hipStreamCreateWithFlags(&p.side[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        p.ok = true;
+    }
+    return &p;
+}
+
+// files [b0, b1) of a shard as a shard of their own (same matrices, offset bases)
+static SharedShard sub_shard(const SharedShard& sh, int b0, int b1) {
+    SharedShard u = sh;
+    u.V = sh.V + b0 * sh.g.sV;
+    u.H = sh.H + b0 * sh.g.sH;
+    u.R = sh.R + b0 * sh.g.sV;
+    u.Upart = sh.Upart + b0 * sh.g.sU;
+    u.rowsum_part = sh.rowsum_part + (long)b0 * sh.g.Kp;
+    u.batch = b1 - b0;
+    return u;
+}
+
+// H update with the current W, then the per-file (V/WH).H^T and row sums of H (K1, K2, K3, K4a on stream s)
+static int shared_gemms(const SharedShard& sh, const float* W, const float* colsumW, const float* hscale, float alpha, float eps,
+                        hipStream_t s) {
     const NmfGeom& g = sh.g;
     int rc;
     // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
@@ -710,13 +756,57 @@ static int shared_step_a(const SharedShard& sh, const float* W, const float* col
     if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, sh.batch, 1, s))) return rc;
     // (H now carries the previous normalisation; K3 below takes no scale, and step B rewrites hscale before anyone reads it again)
     if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, nullptr, 0, sh.R, sh.batch, 1, s))) return rc;
-    if ((rc = launch_rht(g, sh.R, sh.H, sh.Upart, sh.rowsum_part, sh.batch, 1, s))) return rc;
+    return launch_rht(g, sh.R, sh.H, sh.Upart, sh.rowsum_part, sh.batch, 1, s);
+}
+
+// partial (+)= [sum_files Upart || sum_files rowsum_part], files in ascending order (deterministic)
+static int shared_reduce(const SharedShard& sh, float* partial, int accumulate, hipStream_t s) {
+    const NmfGeom& g = sh.g;
     hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)((g.sU + 255) / 256)), dim3(256), 0, s, sh.Upart, g.sU, sh.batch, g.sU,
                        partial, accumulate);
     GCCNMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, sh.rowsum_part, (long)g.Kp, sh.batch,
                        (long)g.Kp, partial + g.sU, accumulate);
     GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// Step A of every shard of a rank: the GEMMs of the shards' file groups dealt out over the main stream and the side streams, joined,
+// then the file-order reductions on the main stream.
+static int shared_step_a_all(const SharedShard* sh, int n, const float* W, const float* colsumW, const float* hscale, float* partial,
+                             float alpha, float eps, hipStream_t s) {
+    int rc;
+    SharedShard units[GCCNMF_MAX_SHARDS * GCCNMF_SHARED_STREAMS];
+    int nu = 0;
+    const int want = gccnmf_tune_shared_groups;
+    for (int i = 0; i < n; ++i) {
+        // Groups pay only when ONE launch over the whole shard cannot fill the chip (fewer than 512 throughput tiles = two per CU:
+        // a 160 s mixture has 313): then the groups' launches, each a fraction of a round, run side by side and the short kernels of
+        // different stages overlap.  A shard that fills the chip by itself loses with groups in lock-step (64 files: 151 k frames/s
+        // as one group, 144 k as two, 130 k as three -- profiles/r03b): one group.
+        const long tiles = (long)sh[i].batch * gccnmf_ceil_div(sh[i].g.N, 64);
+        int groups = tiles >= 512 ? 1 : (int)(tiles / 64);
+        if (groups > sh[i].batch) groups = sh[i].batch;
+        groups = groups < 1 ? 1 : (groups > want ? want : groups);
+        for (int q = 0; q < groups; ++q) units[nu++] = sub_shard(sh[i], (int)((long)sh[i].batch * q / groups), (int)((long)sh[i].batch * (q + 1) / groups));
+    }
+    SidePool* pool = (nu > 1 && want > 1) ? side_pool() : nullptr;
+    const int lanes = pool ? (want < nu ? want : nu) : 1;
+    if (lanes > 1) {
+        if (hipEventRecord(pool->fork, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        for (int l = 1; l < lanes; ++l)
+            if (hipStreamWaitEvent(pool->side[l - 1], pool->fork, 0) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    }
+    for (int u = 0; u < nu; ++u) {
+        const int l = u % lanes;
+        if ((rc = shared_gemms(units[u], W, colsumW, hscale, alpha, eps, l ? pool->side[l - 1] : s))) return rc;
+    }
+    for (int l = 1; l < lanes; ++l) {
+        if (hipEventRecord(pool->join[l - 1], pool->side[l - 1]) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        if (hipStreamWaitEvent(s, pool->join[l - 1], 0) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    }
+    for (int i = 0; i < n; ++i)
+        if ((rc = shared_reduce(sh[i], partial, i > 0, s))) return rc;
     return GCCNMF_OK;
 }
 
@@ -770,7 +860,7 @@ int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* 
     if (!V || !W || !H || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(V, H, workspace, F, N, K, batch, 0);
     float* vec = legacy_vec(workspace, sh);
-    return shared_step_a(sh, W, vec, vec + sh.g.Kp, partial, 0, sparsity_alpha, epsilon, (hipStream_t)stream);
+    return shared_step_a_all(&sh, 1, W, vec, vec + sh.g.Kp, partial, sparsity_alpha, epsilon, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch, void* stream) {
@@ -809,8 +899,7 @@ int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, floa
     for (int it = 0; it < iterations; ++it) {
         // a rank without columns (fewer files than ranks) contributes a zero partial and still follows every W update
         if (nshards == 0 && hipMemsetAsync(partial, 0, sizeof(float) * np, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-        for (int i = 0; i < nshards; ++i)
-            if ((rc = shared_step_a(sh[i], W, colsumW, hscale, partial, i > 0, sparsity_alpha, epsilon, s))) return rc;
+        if (nshards && (rc = shared_step_a_all(sh, nshards, W, colsumW, hscale, partial, sparsity_alpha, epsilon, s))) return rc;
         if (allreduce && allreduce(allreduce_ctx, partial, np, stream) != 0) return GCCNMF_ERR_COLLECTIVE;
         if ((rc = shared_step_b(W, partial, colsumW, hscale, F, K, s))) return rc;
     }

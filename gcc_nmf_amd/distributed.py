@@ -489,16 +489,25 @@ class HipTimeShard(object):
 
     @_on_device
     def overlap_add(self, previous):
+        """-> (segment (S, 2, L) float32, first global sample index of the trimmed output).  The segment is a view of a page-locked
+        buffer that the next call overwrites (61 MB per 160 s of audio: copy it if it must outlive the next step)."""
         e, g = self.e, self.e.g
         nsig = 2 * g.S
-        prev = previous.to(self.device) if previous is not None else torch.zeros((nsig, self.halo, self.n_fft), dtype=torch.float32, device=self.device)
-        frames = torch.cat([prev, e.frames[0]], dim=1).contiguous()                      # [nsig][halo + T_r][n_fft], ascending frames
+        if previous is not None:
+            previous = previous.to(self.device).contiguous()
         L = (g.T - 1) * self.hop + self.n_fft if self.last else g.T * self.hop           # the samples this rank owns
-        y = torch.zeros((nsig, L), dtype=torch.float32, device=self.device)
+        if getattr(self, '_y', None) is None:
+            self._y = torch.zeros((nsig, L), dtype=torch.float32, device=self.device)
+            self._y_host = torch.zeros((nsig, L), dtype=torch.float32).pin_memory()
         gain = np.float32(self.hop / float(self.n_fft) * 2)                              # gccNMFFunctions.py:155
-        _hip.check(e.lib.gccnmf_ola_frames(_ptr(frames), nsig, self.n_fft, self.hop, self.halo + g.T, 1, self.halo * self.hop, L, gain,
-                                           _ptr(y), _stream()), 'gccnmf_ola_frames')
-        return y.view(g.S, 2, L).cpu().numpy(), self.t0 * self.hop - self.n_fft // 2    # centre trim (librosaSTFT.py:283-284)
+        # frames = the previous rank's last `halo` frames, then the own ones, in ascending order -- read from where they are
+        halo = self.halo if previous is not None else 0
+        first = self.halo * self.hop - (self.halo - halo) * self.hop                      # rank 0 has no predecessor: its stream starts at its own frame 0
+        _hip.check(e.lib.gccnmf_ola_frames_halo(_ptr(previous), halo, _ptr(e.frames[0]), nsig, self.n_fft, self.hop, g.T, first, L, gain,
+                                                _ptr(self._y), _stream()), 'gccnmf_ola_frames_halo')
+        self._y_host.copy_(self._y, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._y_host.numpy().reshape(g.S, 2, L), self.t0 * self.hop - self.n_fft // 2    # centre trim (librosaSTFT.py:283-284)
 
     def tdoa_indexes(self):
         return self.e.get_tdoa_indexes()[0]

@@ -50,7 +50,9 @@ int gccnmf_version(void);
  * key 4: 1 (default) = small launches run on the LDS-DMA ring kernel (csrc/gemm_ring.h).  keys 5 / 6: parts of the single-file
  * split-K reductions (W.H / R.H^T).  key 7: 1 = the throughput tile's V / (W.H) epilogue divides IEEE-exactly like numpy.divide
  * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
- * small-launch kernels always divide exactly).  Unknown keys / values: GCCNMF_ERR_ARG. */
+ * small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
+ * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
+ * Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -236,6 +238,11 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
  * single-mixture mode, where a shard's first samples need the previous shard's last n_fft/hop - 1 frames. */
 int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, int batch, int first_sample, int L, float gain,
                       float* y, void* stream);
+
+/* The same for ONE file whose frame sequence is `halo` frames of `prev` [nsig][halo][n_fft] (the previous time shard's last frames; may be
+ * NULL with halo = 0) followed by the T frames of `frames` [nsig][T][n_fft] -- no concatenated copy of the two. */
+int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int nsig, int n_fft, int hop, int T, int first_sample, int L,
+                           float gain, float* y, void* stream);
 
 /* Streaming (real-time) GCC-NMF: one block of `blockSize` new stereo samples per call, Tc = blockSize/hopSize analysis
  * windows.  Replaces GCCNMFProcessor.processFrames (gccNMF/realtime/gccNMFProcessor.py:201-270, a Theano graph in the

@@ -113,7 +113,7 @@ def test_column_blocks_of_one_matrix(N, block):
     Wr, Hr = O.performKLNMF(V, K, iters, 0)
     assert np.linalg.norm(nmf.W() - Wr) < 1e-4 * np.linalg.norm(Wr)
     assert np.linalg.norm(nmf.H()[0] - Hr) < 1e-4 * np.linalg.norm(Hr)
-    assert float(Hd[:, N:].abs().max()) == 0.0 and float(Hd[K:].abs().max()) == 0.0 if ld > N else True      # padding untouched
+    assert ld == N or float(Hd[:, N:].abs().max()) == 0.0                       # the padding columns stay zero
 
 
 def test_library_rccl_communicator_single_rank():
