@@ -197,7 +197,7 @@ __device__ __forceinline__ gemm_i32x4 gemm_buffer_rsrc(const void* wave_uniform_
 // pair m+1 are in flight while pair m is computed and stored (one exposed memory round trip per wave instead of four).
 // Per-row factors (EPI_UPDH: scale / (column sum + alpha + eps); the rank-1 tail column) are NOT loaded here: the
 // workgroup puts them into LDS once, before its main loop (s_rowvec), and finish() reads them as 16-byte groups.
-template <int EPI>
+template <int EPI, int BM = 512>
 struct GemmEpiloguePair {
     static_assert(EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH, "");
     float xa[16], xb[16];          // EPI_DIV: V; EPI_UPDH: old H
@@ -218,7 +218,7 @@ struct GemmEpiloguePair {
         }
     }
 
-    // s_rowvec: [0, 512) = tail column of A (0 without a rank-1 tail), [512, 1024) = EPI_UPDH row factor, indexed by the row
+    // s_rowvec: [0, BM) = tail column of A (0 without a rank-1 tail), [BM, 2 BM) = EPI_UPDH row factor, indexed by the row
     // inside the workgroup tile; tile_row = row_u - (first row of the workgroup tile)
     // oka / okb: this lane's column (col_a, col_a + 32) is inside N -- the only predicate of the lean path, two exec-mask
     // regions per pair (the last column tile of a file is ragged: N = 1244 = 19 x 64 + 28)
@@ -232,7 +232,7 @@ struct GemmEpiloguePair {
         for (int g = 0; g < 4; ++g) {
             gemm_f32x4 tav = {0.f, 0.f, 0.f, 0.f}, gv = tav;
             if (EPI == EPI_STORE || EPI == EPI_UPDH) tav = *(const gemm_f32x4*)(s_rowvec + tile_row + 8 * g + 4 * hh);
-            if (EPI == EPI_UPDH) gv = *(const gemm_f32x4*)(s_rowvec + 512 + tile_row + 8 * g + 4 * hh);
+            if (EPI == EPI_UPDH) gv = *(const gemm_f32x4*)(s_rowvec + BM + tile_row + 8 * g + 4 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * g + i;
@@ -366,9 +366,14 @@ __device__ __forceinline__ void gemm_epilogue_update_w_full(const GemmArgs& p, i
     }
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool TAIL>
+// TM = 32-row MFMA tiles per wave: 4 = the 512 x 64 throughput tile; 2 = the HALF-HEIGHT tile (256 x 64, 64 x 64 per wave) that the
+// launcher gives to the files of a launch's last, partial round (same k order per output element: bitwise the same result).
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM = 4>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
-    constexpr int BK = 16, TM = 4, BM = 512, BN = 64;
+    static_assert(TM == 4 || TM == 2, "");
+    static_assert(TM == 4 || EPI != EPI_UPDW, "the fused W update owns all rows of its atoms: full-height tiles only");
+    constexpr int BK = 16, BM = 128 * TM, BN = 64, RW = 32 * TM;      // RW: rows per wave
+    constexpr int NA = 2 * TM;                                         // 1 KB LDS-DMA pieces of the A tile per wave
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
     constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);   // K1 (R = V / (W.(s*H))) carries a lazy row scale on its B operand
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
     }
+    file += p.file0;
     // (the integer divisions above run on the VALU: without the readfirstlanes every value derived from file / tile -- all
     // row pointers, descriptors and scalar offsets below -- stays in VGPRs and each buffer access becomes a waterfall loop)
     file = __builtin_amdgcn_readfirstlane(file);
@@ -405,25 +411,26 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     }
     const int wm = wave, wn = 0;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int arow = wm * 128 + l31, bcol = wn * 64 + l31;
+    const int arow = wm * RW + l31, bcol = wn * 64 + l31;
 
     const float* __restrict__ A = p.A + file * p.sA;
     const float* __restrict__ B = p.B + file * p.sB;
     const float* __restrict__ bscale = (SCALE && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
-    const bool wave_active = (row0 + wm * 128) < p.M;
+    const bool wave_active = (row0 + wm * RW) < p.M;
     const bool do_tail = TAIL && (tm == 0);
     const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
 
-    // per-lane source offsets (elements) of this wave's DMA pieces: 8 of A, 1 of B
-    unsigned offA[8], offB;                                            // bytes from the (wave-uniform) k-tile origin
+    // per-lane source offsets (elements) of this wave's DMA pieces: NA of A, 1 of B
+    unsigned offA[NA], offB;                                           // bytes from the (wave-uniform) k-tile origin
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int piece = wave * 8 + i;                                // 1 KB pieces of the A tile
+    for (int i = 0; i < NA; ++i) {
+        const int piece = wave * NA + i;                               // 1 KB pieces of the A tile
         if (A_KC) {
             const int row = piece * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(piece * 16 + (lane >> 2));
             offA[i] = 4u * (unsigned)(min(row0 + row, p.a_clamp) * p.lda + 4 * c);
         } else {
-            const int kk = piece >> 1, col = (piece & 1) * 256 + lane * 4;
+            constexpr int PPR = BM / 256;                              // pieces per k row of the [16][BM] image
+            const int kk = piece / PPR, col = (piece % PPR) * 256 + lane * 4;
             offA[i] = 4u * (unsigned)(kk * p.lda + min(row0 + col, p.a_clamp));
         }
     }
@@ -452,15 +459,15 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const float* __restrict__ tail_src = A + (long)p.tail_row * p.lda;
     const unsigned side_off = 16u * (unsigned)(lane & 3);
 
-    // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0-7 = this wave's share of A, 8 = of B, 9 = the tail row
+    // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0 .. NA-1 = this wave's share of A, NA = of B, NA+1 = the tail row
     // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
     auto dma_piece = [&](const int piece, const int kt, const int buf) {
 #ifdef GEMM_DMA_SKIP_FROM
         if (piece >= GEMM_DMA_SKIP_FROM) return;                    // timing experiment (results invalid): fewer pieces per k-tile
 #endif
-        if (piece < 8) {
-            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece], lds0 + 4 * (buf * SBUF + (wave * 8 + piece) * 256));
-        } else if (piece == 8) {
+        if (piece < NA) {
+            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece < NA ? piece : 0], lds0 + 4 * (buf * SBUF + (wave * NA + piece) * 256));
+        } else if (piece == NA) {
             gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb), offB, lds0 + 4 * (buf * SBUF + SA + wave * 256));
         } else {
             if (TAIL || SCALE) {
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             }
         }
     };
-    constexpr int NPIECES = 10;
+    constexpr int NPIECES = NA + 2;
     // how the pieces are dealt out over the 16 MFMA pairs of group 0 -- 0: all before the first MFMA; 1: one per pair;
     // 2: two per three pairs.  While every piece carried a 64-bit VALU address add this mattered (W.H 0.816 / 0.698 / 0.699 ms,
     // R.H^T 0.777 / 0.779 / 0.750); with the saddr form the three are within 2 % (0.664 / 0.654 / 0.654, 0.644 / 0.624 / 0.624).
@@ -572,12 +579,12 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     // row factors of the lean epilogue (visible after the prologue barrier; read only after the main loop)
     if constexpr (EPI == EPI_STORE || EPI == EPI_UPDH) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < BM / 256; ++i) {
             const int lr = tid + 256 * i, row = min(row0 + lr, p.M - 1);
             s_rowvec[lr] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
             if (EPI == EPI_UPDH) {
                 const float rd = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
-                s_rowvec[512 + lr] = p.E1 ? p.E1[file * p.sE1 + row] * rd : rd;
+                s_rowvec[BM + lr] = p.E1 ? p.E1[file * p.sE1 + row] * rd : rd;
             }
         }
     }
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 #endif
     if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
 
-    if (EPI == EPI_UPDW) {
+    if constexpr (EPI == EPI_UPDW) {
         // launch_rht_update_w guarantees M % 128 == 0 and N % 64 == 0 (a second, generic variant in this kernel would
         // double the live ranges of the accumulators and spill the main loop)
         gemm_epilogue_update_w_full<TAIL>(p, file, col0, tid, wm, l31, hh, wave_active, acc, tail_acc, rowsum_acc, smem);
@@ -752,13 +759,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         return;
     }
     if (wave_active) {
-        const int row_w = row0 + wm * 128;                          // wave-uniform
+        const int row_w = row0 + wm * RW;                           // wave-uniform
         bool lean = false;
         if constexpr (EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH) {
-            lean = row_w + 128 <= p.M;                              // all four tile pairs of the wave have all their rows
+            lean = row_w + RW <= p.M;                               // all tile pairs of the wave have all their rows
             if (lean) {
-                GemmEpiloguePair<EPI> e0, e1;
-                const int ca = col0 + l31, tr = wm * 128;
+                GemmEpiloguePair<EPI, BM> e0, e1;
+                const int ca = col0 + l31, tr = wm * RW;
                 const bool oka = ca < p.N, okb = ca + 32 < p.N;
                 const long cb = 4L * p.ldc * (p.M + (TAIL ? 1 : 0));
                 float ba = 0.f, bb = 0.f;
@@ -770,11 +777,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                 }
                 e0.finish(p, file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
                 if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-                e0.load(p, file, row_w + 64, hh, ca, cb);
+                if constexpr (TM == 4) e0.load(p, file, row_w + 64, hh, ca, cb);
                 e1.finish(p, file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1], oka, okb, cb);
-                e1.load(p, file, row_w + 96, hh, ca, cb);
-                e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
-                e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
+                if constexpr (TM == 4) {
+                    e1.load(p, file, row_w + 96, hh, ca, cb);
+                    e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
+                    e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
+                }
                 if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
             }
         }
@@ -810,13 +819,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool TAIL>
-static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
-    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
-    if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
-    a.ablate = gccnmf_tune_ablate;
-    a.exact_div = gccnmf_tune_exact_div;
-    a.tiles_m = gccnmf_ceil_div(a.M, 512);
+// One launch of the LDS-DMA tile over the files [a.file0, a.file0 + a.batch)
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM>
+static int gccnmf_launch_gemm_dma_tm(GemmArgs a, hipStream_t stream) {
+    a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     const int tiles = a.tiles_m * a.tiles_n;
     int grid;
@@ -828,7 +834,50 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
         grid = a.batch * tiles;
     }
     a.trace = (gccnmf_trace_buf && 5 * grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;   // timeline + 4 per-wave probe rows
-    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, TM>), dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+// A launch is whole rounds of 512 workgroups (two per CU) plus a partial one, and a partial round costs 0.135 ms however few
+// workgroups it holds (a workgroup alone on its CU: profiles/r02k_files_sweep.txt).  When that pays, the files the partial round
+// would take run as a second launch of HALF-HEIGHT tiles instead: twice the workgroups at half the length (80 files: 3 rounds + 64
+// tiles -> 76 files + 4 files as 160 half tiles, one per CU for a third of the time); a launch of less than one round may run
+// entirely on half-height tiles (16 files: 640 of them, three per CU).  Whole files only,
+// same k order per output element, so a file's bits do not depend on which launch it rides in.  Tuning key 9 (default on).
+extern int gccnmf_tune_tail_split;
+template <bool A_KC, bool B_KC, int EPI, bool TAIL>
+static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
+    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
+    if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
+    a.ablate = gccnmf_tune_ablate;
+    a.exact_div = gccnmf_tune_exact_div;
+    if constexpr (EPI != EPI_UPDW) {
+        const long tpf = (long)gccnmf_ceil_div(a.M, 512) * gccnmf_ceil_div(a.N, 64);     // throughput tiles per file
+        const long total = tpf * a.batch, rounds = total / 512;
+        // Decided by a cost model in units of one paired round of full tiles = 250 (measured at Kd = 1024: 0.25 ms; everything scales
+        // with Kd alike): a partial round of <= 256 full tiles costs 135 (one workgroup alone per CU), a larger one a whole round;
+        // half-height workgroups (130-170 VGPRs, 43 KB of LDS: three per CU) cost 85 up to one per CU, 135 up to two, 190 up to
+        // three; a second launch costs 10 (profiles/r03f_files_sweep.txt).
+        if (gccnmf_tune_tail_split && !gccnmf_trace_buf && a.M > 256) {
+            auto full_cost = [](long tiles) { const long r = tiles % 512; return (tiles / 512) * 250 + (r == 0 ? 0 : r <= 256 ? 135 : 250); };
+            auto half_cost = [](long halves) { return halves <= 256 ? 85L : halves <= 512 ? 135L : halves <= 768 ? 190L : 1L << 40; };
+            if (rounds == 0) {                                       // less than one round: all of it as half-height tiles?
+                if (half_cost(2 * total) < full_cost(total)) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+            } else {
+                const int head = (int)(rounds * 512 / tpf);          // whole files that fit the whole rounds
+                const int rest = a.batch - head;
+                if (head >= 8 && rest >= 1 && full_cost(head * tpf) + half_cost(2 * rest * tpf) + 10 < full_cost(total)) {
+                    GemmArgs h = a, t = a;
+                    h.batch = head;
+                    t.batch = rest;
+                    t.file0 = a.file0 + head;
+                    int rc = gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(h, stream);
+                    if (rc) return rc;
+                    return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(t, stream);
+                }
+            }
+        }
+    }
+    return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(a, stream);
 }

@@ -17,6 +17,7 @@
 int gccnmf_tune_ablate = 0;
 #define GCCNMF_SHARED_STREAMS 4
 int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
+int gccnmf_tune_tail_split = 1;       // key 9: the files of a launch's partial last round run as half-height tiles (gemm_dma.h)
 int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
@@ -44,6 +45,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 4) {
         gccnmf_tune_ring = value ? 1 : 0;
+        return GCCNMF_OK;
+    }
+    if (key == 9 && (value == 0 || value == 1)) {
+        gccnmf_tune_tail_split = value;
         return GCCNMF_OK;
     }
     if (key == 8 && value >= 1 && value <= GCCNMF_SHARED_STREAMS) {

@@ -52,7 +52,8 @@ int gccnmf_version(void);
  * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
  * small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
  * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
- * Unknown keys / values: GCCNMF_ERR_ARG. */
+ * key 9: 1 (default) = the files of a throughput-tile launch's partial last round run as a second launch of half-height tiles
+ * (bitwise the same results).  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */

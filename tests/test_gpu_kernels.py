@@ -300,6 +300,35 @@ def test_klnmf_batch_is_file_independent(hip):
     assert rel(Wp[8, :F, :K], Wr) < 1e-4 and rel(Hp[8, :K, :N], Hr) < 1e-4
 
 
+@pytest.mark.parametrize('F,T,K,B,flags', [(513, 622, 64, 26, 0), (513, 330, 512, 50, 0), (513, 200, 1024, 70, 2)])
+def test_half_height_tiles_of_the_last_round_are_bitwise(hip, F, T, K, B, flags):
+    """Tuning key 9: when a throughput-tile launch ends in a partial round of at most 256 tiles, the files of that round run as a
+    second launch of half-height (256 x 64) tiles.  Same k order per output element: W and H are bit for bit those of the one-launch
+    form (K1/K3 at 26 x 20 = 520 tiles; the H update at K = 512, 50 x 11 = 550; the unfused R.H^T at K = 1024, 70 x 16 = 1120)."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
+    N = 2 * T
+    g = Geometry(F, T, K)
+    rng = np.random.RandomState(B)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    dV = padded(V, (B, g.Fp, g.Np), 'cuda')
+    outs = []
+    try:
+        for split in (0, 1):
+            assert lib.gccnmf_set_tuning(9, split) == 0
+            dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
+            dH = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
+            ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
+            assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, 3, 0.1, 1e-16, flags, stream()) == 0
+            outs.append((dW.cpu().numpy(), dH.cpu().numpy()))
+    finally:
+        lib.gccnmf_set_tuning(9, 1)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    Wr, Hr = O.performKLNMF(V[B - 1], K, 3, 0.1)                      # a file of the half-height launch against the oracle
+    assert rel(outs[1][0][B - 1, :F, :K], Wr) < 1e-4 and rel(outs[1][1][B - 1, :K, :N], Hr) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------------
 # localisation, scores, masks, reconstruction
 # ------------------------------------------------------------------------------------------------
