@@ -456,22 +456,32 @@ def main():
             t1 = time.perf_counter()
             r = O.runGCCNMF(xs[0], sr, 1024, a.hop, 128, 1.0, 3, dictionarySize=K, numIterations=iters, return_intermediates=True)
             return time.perf_counter() - t1, r
-        # best of 3 after one warm-up, all host cores; plus one BLAS thread (OPENBLAS_NUM_THREADS=1 equivalent)
+        # best of 3 after one warm-up on all host cores, and one BLAS thread (OPENBLAS_NUM_THREADS=1 equivalent).  On
+        # a 256-CPU box OpenBLAS's 128 threads are SLOWER than one on these matrix sizes (measured 183 vs 285 frames/s), so the
+        # reported baseline is the best over a small thread sweep -- the CPU at its best, not at its default.
         oracle_run()
         runs = [oracle_run() for _ in range(3)]
-        dt, r = min(runs, key=lambda v: v[0])
-        with threadpool_limits(limits=1):
-            dt1, _ = oracle_run()
-        out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
+        dt_all, r = min(runs, key=lambda v: v[0])
+        sweep = {int(threads): dt_all}
+        for th in (1, 4, 16, 64):
+            if th < threads:
+                with threadpool_limits(limits=th):
+                    sweep[th] = min(oracle_run()[0] for _ in range(2))
+        best_th = min(sweep, key=sweep.get)
+        dt = sweep[best_th]
+        out['cpu_baseline'] = {'value': g.T / dt, 'unit': 'frames/s', 'cores': int(best_th), 'kind': 'port',
                                'sample': '1 of the %d files (%d stereo frames), same parameters, NumPy/OpenBLAS oracle PORT of the reference '
                                          '(oracle/gccnmf_oracle.py; its angular-spectrum and score contractions are GEMM restatements, '
-                                         'so it is FASTER than the reference code): best of 3 after one warm-up, %.1f s each.  The reference '
-                                         'checkout cannot travel with the repository; `reference_on_gpu_box` is the kept record of its '
-                                         "unmodified functions timed on a GPU box's host cores (scripts/time_reference_cpu.py, checkout "
-                                         'staged for that one call)' % (B, g.T, dt),
-                               'runs_s': [v[0] for v in runs], 'host_cpus': os.cpu_count(),
-                               'single_thread': {'value': g.T / dt1, 'unit': 'frames/s', 'cores': 1, 'seconds': dt1,
-                                                 'how': 'threadpoolctl.threadpool_limits(1) around the same call (one BLAS thread)'}}
+                                         'so it is FASTER than the reference code): warm-up, then best run per BLAS thread count, best count '
+                                         'reported (%.1f s per run).  The reference checkout cannot travel with the repository; '
+                                         "`reference_on_gpu_box` is the kept record of its unmodified functions timed on a GPU box's host cores "
+                                         '(scripts/time_reference_cpu.py, checkout staged for that one call)' % (B, g.T, dt),
+                               'host_cpus': os.cpu_count(),
+                               'frames_per_s_by_blas_threads': {str(k): g.T / v for k, v in sorted(sweep.items())},
+                               'all_cores': {'value': g.T / dt_all, 'cores': int(threads), 'runs_s': [v[0] for v in runs],
+                                             'how': 'default OpenBLAS thread pool, best of 3 after one warm-up (SURVEY 8d)'},
+                               'single_thread': {'value': g.T / sweep[1], 'unit': 'frames/s', 'cores': 1, 'seconds': sweep[1],
+                                                 'how': 'threadpoolctl.threadpool_limits(1) around the same call (one BLAS thread)'} if 1 in sweep else None}
         rec = os.path.join(REPO, 'profiles', 'reference_cpu_on_gpu_box.json')
         if os.path.exists(rec) and K == 1024 and iters == 100 and a.hop == 256 and a.seconds == 10.0:
             r0 = json.load(open(rec))

@@ -384,14 +384,27 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const int tiles = p.tiles_m * p.tiles_n;
     int file, tile;
     if (p.xcd_affine) {
-        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the file-major tile list (chunk = xcd_affine = ceil(total / 8)):
-        // balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles on XCD 0 and 3 on the others), and a file
-        // still sits on one XCD (or straddles two neighbours)
+        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the tile list (chunk = xcd_affine = ceil(total / 8)) taken in
+        // the file order 0, 8, 16, ... | 1, 9, ... : balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles
+        // on XCD 0 and 3 on the others), a file still sits on one XCD (or straddles two neighbours), and for a multiple of 8 files it
+        // is exactly the map of rounds 1-2 (XCD x <- files x, x+8, ...), which is 3 % faster at 64 files than contiguous files per
+        // XCD (K3 0.645 vs 0.668 ms, A/B on one box: profiles/r03_ab_xcd_map.txt)
+#ifdef GEMM_XCD_FILE_GRANULAR      // A/B build: the file-granular map of rounds 1-2 (file = xcd + 8 j)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        file = xcd + 8 * (slot / tiles);
+        tile = slot % tiles;
+        if (file >= p.batch) return;
+#else
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int idx = xcd * p.xcd_affine + slot;
         if (idx >= p.batch * tiles) return;
-        file = idx / tiles;
-        tile = idx - file * tiles;
+        // position q in the file order 0, 8, 16, ... | 1, 9, 17, ... | ... (files of one residue class mod 8 are neighbours)
+        const int q = idx / tiles;
+        tile = idx - q * tiles;
+        const int n_full = p.batch >> 3, rem = p.batch & 7, big = rem * (n_full + 1);
+        const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
+        file = cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
+#endif
     } else {
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
@@ -827,8 +840,13 @@ static int gccnmf_launch_gemm_dma_tm(GemmArgs a, hipStream_t stream) {
     const int tiles = a.tiles_m * a.tiles_n;
     int grid;
     if (a.xcd_affine && a.batch >= 8) {
+#ifdef GEMM_XCD_FILE_GRANULAR
+        a.xcd_affine = 1;
+        grid = 8 * gccnmf_ceil_div(a.batch, 8) * tiles;
+#else
         a.xcd_affine = gccnmf_ceil_div(a.batch * tiles, 8);     // tiles per XCD
         grid = 8 * a.xcd_affine;
+#endif
     } else {
         a.xcd_affine = 0;
         grid = a.batch * tiles;

@@ -455,14 +455,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gccnmf_gemm_kernel(GemmArgs p)
     if (p.xcd_affine) {
         // blocks b, b+8, b+16, ... land on XCD b%8 (observed dispatch order): keep every tile of
         // a file on one XCD so its W/H/R panels are shared through that XCD's L2.
-        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the file-major tile list (chunk = xcd_affine = ceil(total / 8)):
-        // balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles on XCD 0 and 3 on the others), and a file
-        // still sits on one XCD (or straddles two neighbours)
+        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the tile list (chunk = xcd_affine = ceil(total / 8)) taken in
+        // the file order 0, 8, 16, ... | 1, 9, ... : balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles
+        // on XCD 0 and 3 on the others), a file still sits on one XCD (or straddles two neighbours), and for a multiple of 8 files it
+        // is exactly the map of rounds 1-2 (XCD x <- files x, x+8, ...), which is 3 % faster at 64 files than contiguous files per
+        // XCD (K3 0.645 vs 0.668 ms, A/B on one box: profiles/r03_ab_xcd_map.txt)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int idx = xcd * p.xcd_affine + slot;
         if (idx >= p.batch * tiles) return;
-        file = idx / tiles;
-        tile = idx - file * tiles;
+        // position q in the file order 0, 8, 16, ... | 1, 9, 17, ... | ... (files of one residue class mod 8 are neighbours)
+        const int q = idx / tiles;
+        tile = idx - q * tiles;
+        const int n_full = p.batch >> 3, rem = p.batch & 7, big = rem * (n_full + 1);
+        const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
+        file = cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
     } else {
         file = blockIdx.x / tiles;
         tile = blockIdx.x - file * tiles;
