@@ -302,14 +302,28 @@ class HipSharedColumns(_SharedRun):
         return [self.Hd[:self.K, :self.N].cpu().numpy()]
 
 
-class CompositeSharedNMF(object):
-    """Several shards of one rank behind the begin / step_a / step_b / finish protocol: their [num || den] partials are added (fixed
-    order) before the all-reduce and every member applies the same reduced buffer.  Lets one rank hold file groups of different
-    widths (``HipSharedNMF`` needs equal N per object)."""
+class CompositeSharedNMF(_SharedRun):
+    """Several ``HipSharedNMF`` members of one rank -- file groups of DIFFERENT widths (a member needs equal N per object) -- trained
+    as one: run() hands every member's files to ONE gccnmf_klnmf_shared_run call as separate shards (their [num || den] partials are
+    added in member order before the all-reduce), with the first member's W, partial and vector scratch; the other members' W are
+    synchronised afterwards.  The begin / step_a / step_b / finish protocol is kept for hosts that own the collective."""
 
     def __init__(self, members):
         self.members = list(members)
-        self.partial = self.members[0].partial
+        first = self.members[0]
+        if any((m.F, m.K, m.alpha, m.eps, m.device) != (first.F, first.K, first.alpha, first.eps, first.device) for m in self.members):
+            raise ValueError('members must share F, K, the regularisation and the device')
+        self.lib, self.device, self.F, self.K, self.alpha, self.eps = first.lib, first.device, first.F, first.K, first.alpha, first.eps
+        self.Wd, self.partial, self.vec = first.Wd, first.partial, first.vec
+
+    def _shards(self):
+        return sum([m._shards() for m in self.members], [])
+
+    def run(self, numIterations, group=None):
+        _SharedRun.run(self, numIterations, group)
+        for m in self.members[1:]:
+            m.Wd.copy_(self.Wd)
+        return self
 
     def begin(self):
         for m in self.members:
@@ -329,9 +343,6 @@ class CompositeSharedNMF(object):
     def finish(self):
         for m in self.members:
             m.finish()
-
-    def W(self):
-        return self.members[0].W()
 
 
 def train_shared_dictionary(local, numIterations, group=None):

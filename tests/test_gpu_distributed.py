@@ -116,6 +116,26 @@ def test_column_blocks_of_one_matrix(N, block):
     assert ld == N or float(Hd[:, N:].abs().max()) == 0.0                       # the padding columns stay zero
 
 
+def test_file_groups_of_different_widths_as_one_training():
+    """CompositeSharedNMF: two groups of files with different N in ONE gccnmf_klnmf_shared_run call (two shards) == performKLNMF on
+    the concatenation, and bitwise the host-driven protocol over the same members."""
+    from gcc_nmf_amd.distributed import CompositeSharedNMF, HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    F, K, cols = 257, 96, [70, 70, 70, 130, 130]
+    V = _problem(F, K, cols, seed=21)
+    W0, H0 = shared_initial_factors(F, cols, K, range(5), mode='concat')
+
+    def build():
+        return CompositeSharedNMF([HipSharedNMF(V[:3], W0, H0[:3]), HipSharedNMF(V[3:], W0, H0[3:])])
+    a, b = build(), build()
+    train_shared_dictionary(a, 7)                         # one C call, two shards
+    _protocol([b], 7)
+    assert np.array_equal(a.W(), b.W()) and np.array_equal(a.members[1].W(), a.W())
+    Ha = np.concatenate(a.members[0].H() + a.members[1].H(), axis=1)
+    assert np.array_equal(Ha, np.concatenate(b.members[0].H() + b.members[1].H(), axis=1))
+    Wr, Hr = O.performKLNMF(np.concatenate(V, axis=1), K, 7, 0)
+    assert np.linalg.norm(a.W() - Wr) < 1e-4 * np.linalg.norm(Wr) and np.linalg.norm(Ha - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
 def test_library_rccl_communicator_single_rank():
     """csrc/collective.hip on hardware: librccl bound by dlopen, a 1-rank communicator from a unique id, ncclAllReduce enqueued from C
     inside gccnmf_klnmf_shared_run -- same bits as the run without a collective."""
