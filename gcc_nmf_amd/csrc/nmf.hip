@@ -674,6 +674,8 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
 struct SharedShard {
     const float* V;
     float *H, *R, *Upart, *rowsum_part;
+    float *parts, *rowsum_parts;      // one file in the plain layout: scratch of the latency path's split-K partials, else nullptr
+    bool latency;                     // ... and the current tuning sends it down that path
     NmfGeom g;
     int batch;
     long r_floats;
@@ -687,9 +689,20 @@ static bool shared_shard_ok(int F, int N, int K, int batch, int ld) {
     return true;
 }
 
+// A shard that is ONE file in the plain layout (a rank's whole, short column range: at eight ranks a 160 s mixture leaves 20 s each)
+// is latency-bound exactly like one mixture alone: it takes that path's split-K launches (W.H over the atoms, R.H^T over the columns,
+// csrc/nmf.hip "One file alone") instead of 64-80 workgroup launches with 64-78-step chains.
+static bool shared_single_file_layout(const NmfGeom& g, int batch, int ld) { return batch == 1 && (ld == 0 || ld == g.Np); }   // sizes the scratch
+static bool shared_latency_shard(const NmfGeom& g, int batch, int ld) {                                                        // decides per call
+    return shared_single_file_layout(g, batch, ld) && single_file_split(g, 1, g.Kp, gccnmf_tune_wh_splits) &&
+           single_file_split(g, 1, g.Np, gccnmf_tune_rht_splits);
+}
+static long shared_split_floats(const NmfGeom& g) { return GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp); }
+
 static SharedShard make_shard(const float* V, float* H, float* ws, int F, int N, int K, int batch, int ld) {
     SharedShard sh;
     sh.g = make_geom(F, N, K);
+    sh.latency = shared_latency_shard(sh.g, batch, ld);
     if (ld > 0) {
         sh.g.ld = ld;
         sh.g.sV = sh.g.sH = N;              // the next file is the next column block
@@ -699,6 +712,12 @@ static SharedShard make_shard(const float* V, float* H, float* ws, int F, int N,
     sh.R = ws;
     sh.Upart = sh.R + sh.r_floats;
     sh.rowsum_part = sh.Upart + (long)batch * sh.g.sU;
+    sh.parts = sh.rowsum_parts = nullptr;
+    if (shared_single_file_layout(sh.g, batch, ld)) {
+        sh.g = make_geom(F, N, K);              // (ld == Np: the plain single-file geometry; strides are irrelevant for one file)
+        sh.parts = sh.rowsum_part + (long)batch * sh.g.Kp;
+        sh.rowsum_parts = sh.parts + GCCNMF_SPLITS * (sh.g.sV > sh.g.sU ? sh.g.sV : sh.g.sU);
+    }
     return sh;
 }
 
@@ -755,6 +774,12 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
                         hipStream_t s) {
     const NmfGeom& g = sh.g;
     int rc;
+    if (sh.latency) {                           // one file alone: the split-K launches of the latency path
+        if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, hscale, sh.parts, sh.R, s))) return rc;
+        if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, 1, 0, s))) return rc;
+        if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, nullptr, sh.parts, sh.R, s))) return rc;
+        return launch_rht_split(g, sh.R, sh.H, sh.parts, sh.rowsum_parts, s);
+    }
     // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
     // through that XCD's L2), exactly as the per-file-dictionary path does
     if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, hscale, 0, sh.R, sh.batch, 1, s))) return rc;
@@ -767,11 +792,14 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
 // partial (+)= [sum_files Upart || sum_files rowsum_part], files in ascending order (deterministic)
 static int shared_reduce(const SharedShard& sh, float* partial, int accumulate, hipStream_t s) {
     const NmfGeom& g = sh.g;
-    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)((g.sU + 255) / 256)), dim3(256), 0, s, sh.Upart, g.sU, sh.batch, g.sU,
-                       partial, accumulate);
+    // (one file alone: the "files" are the parts of its split R.H^T reduction, added in ascending order)
+    const float* U = sh.latency ? sh.parts : sh.Upart;
+    const float* rowsum = sh.latency ? sh.rowsum_parts : sh.rowsum_part;
+    const int n = sh.latency ? gccnmf_tune_rht_splits : sh.batch;
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)((g.sU + 255) / 256)), dim3(256), 0, s, U, g.sU, n, g.sU, partial, accumulate);
     GCCNMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, sh.rowsum_part, (long)g.Kp, sh.batch,
-                       (long)g.Kp, partial + g.sU, accumulate);
+    hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, rowsum, (long)g.Kp, n, (long)g.Kp,
+                       partial + g.sU, accumulate);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
@@ -833,18 +861,20 @@ static int shared_finish(const SharedShard* sh, int n, float* hscale, int K, hip
 }
 
 // the four-call protocol's workspace: one default-layout shard's scratch | colsumW [Kp] | hscale [Kp]
-static float* legacy_vec(float* ws, const SharedShard& sh) { return sh.rowsum_part + (long)sh.batch * sh.g.Kp; }
+static float* legacy_vec(float* ws, const SharedShard& sh) {
+    return sh.parts ? sh.rowsum_parts + GCCNMF_SPLITS * (long)sh.g.Kp : sh.rowsum_part + (long)sh.batch * sh.g.Kp;
+}
 
 long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch) {
     if (!shared_shard_ok(F, N, K, batch, 0)) return -1;
     NmfGeom g = make_geom(F, N, K);
-    return (long)batch * (g.sV + g.sU + g.Kp) + 2L * g.Kp;
+    return (long)batch * (g.sV + g.sU + g.Kp) + (shared_single_file_layout(g, batch, 0) ? shared_split_floats(g) : 0) + 2L * g.Kp;
 }
 
 long gccnmf_klnmf_shared_shard_workspace_floats(int F, int N, int K, int batch, int ld) {
     if (!shared_shard_ok(F, N, K, batch, ld)) return -1;
     NmfGeom g = make_geom(F, N, K);
-    return shared_r_floats(g, batch, ld) + (long)batch * (g.sU + g.Kp);
+    return shared_r_floats(g, batch, ld) + (long)batch * (g.sU + g.Kp) + (shared_single_file_layout(g, batch, ld) ? shared_split_floats(g) : 0);
 }
 
 long gccnmf_klnmf_shared_partial_floats(int F, int K) {

@@ -282,9 +282,14 @@ class HipSharedColumns(_SharedRun):
         assert self.ld % 64 == 0 and self.ld >= self.N and V.is_contiguous() and H.is_contiguous() and W.is_contiguous()
         self.V, self.Hd, self.Wd = V, H, W
         if block is None:
-            # R.H^T has Kp/64 workgroups per block: aim at >= 512 (two per CU), blocks of at least 256 columns (16 k-tiles)
-            want = max(1, -(-512 // (g.Kp // 64)))
-            block = max(256, 64 * (self.N // (64 * want)))
+            if self.ld <= 4096:
+                # a short column range (at eight ranks a 160 s mixture leaves 20 s = 2494 columns each) is latency-bound like one
+                # mixture alone: ONE block, which the library sends down that path's split-K launches (csrc/nmf.hip)
+                block = self.ld
+            else:
+                # R.H^T has Kp/64 workgroups per block: aim at >= 512 (two per CU), blocks of at least 256 columns (16 k-tiles)
+                want = max(1, -(-512 // (g.Kp // 64)))
+                block = max(256, 64 * (self.N // (64 * want)))
         if block % 64:
             raise ValueError('column blocks must be multiples of 64 columns')
         self.block = int(block)

@@ -136,6 +136,30 @@ def test_file_groups_of_different_widths_as_one_training():
     assert np.linalg.norm(a.W() - Wr) < 1e-4 * np.linalg.norm(Wr) and np.linalg.norm(Ha - Hr) < 1e-4 * np.linalg.norm(Hr)
 
 
+def test_short_column_range_takes_the_latency_path():
+    """A rank's whole, short column range (one 'file' in the plain layout, K and N >= 512) runs the split-K launches of the
+    one-mixture-alone path inside gccnmf_klnmf_shared_run: == performKLNMF, == the column-block form to summation order, and
+    repeatable bit for bit."""
+    from gcc_nmf_amd.distributed import HipSharedColumns
+    from gcc_nmf_amd.engine import Geometry, klnmf_initial_factors, padded
+    F, N, K, iters = 513, 1244, 512, 8
+    V = _problem(F, K, [N], seed=4)[0]
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    g = Geometry(F, 1, K)
+    ld = -(-N // 64) * 64
+    outs = []
+    for block in (None, None, 256):
+        Vd, Hd, Wd = padded(V, (g.Fp, ld), 'cuda'), padded(H0, (g.Kp, ld), 'cuda'), padded(W0, (g.Fp, g.Kp), 'cuda')
+        nmf = HipSharedColumns(Vd, Hd, Wd, F, N, K, block=block)
+        nmf.run(iters)
+        outs.append((nmf.W(), nmf.H()[0], nmf.blocks))
+    assert outs[0][2] == [(0, N, 1)] and len(outs[2][2]) == 2
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.linalg.norm(outs[0][0] - outs[2][0]) < 1e-5 * np.linalg.norm(outs[2][0])
+    Wr, Hr = O.performKLNMF(V, K, iters, 0)
+    assert np.linalg.norm(outs[0][0] - Wr) < 1e-4 * np.linalg.norm(Wr) and np.linalg.norm(outs[0][1] - Hr) < 1e-4 * np.linalg.norm(Hr)
+
+
 def test_library_rccl_communicator_single_rank():
     """csrc/collective.hip on hardware: librccl bound by dlopen, a 1-rank communicator from a unique id, ncclAllReduce enqueued from C
     inside gccnmf_klnmf_shared_run -- same bits as the run without a collective."""
