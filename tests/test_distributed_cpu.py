@@ -160,3 +160,37 @@ def test_time_sharded_two_ranks_gloo(tmp_path):
     assert int(r[0]['start']) + r[0]['seg'].shape[2] == int(r[1]['start'])          # the segments tile the output
     assert np.abs(y2 - y1).max() < 1e-5 * np.abs(y1).max()
     assert np.sqrt(np.mean((y2 - y1) ** 2)) < 1e-6
+
+
+# ---- the all-reduce hook of gccnmf_klnmf_shared_run over a non-RCCL backend ------------------------------------------------------
+def _hook_worker(rank, world, port, out_dir):
+    import ctypes
+    import sys
+    sys.path.insert(0, REPO)
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.distributed import collective_hook
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    try:
+        partial = torch.full((1000,), float(rank + 1))
+        fn, ctx, keep, what = collective_hook(partial)
+        assert ctx is None and 'gloo' in what
+        call = ctypes.cast(fn, _hip.ALLREDUCE_FN)                      # what the C loop does once per iteration
+        assert call(None, partial.data_ptr(), partial.numel(), None) == 0
+        assert call(None, partial.data_ptr() + 4, partial.numel(), None) == 1 and isinstance(keep[1][0], RuntimeError)   # carried out, not raised through C
+        np.save(os.path.join(out_dir, 'hook_rank%d.npy' % rank), partial.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_hook_is_a_host_callback_over_gloo(tmp_path):
+    """distributed.collective_hook with a gloo group: the gccnmf_allreduce_fn handed to gccnmf_klnmf_shared_run is a ctypes callback
+    that runs dist.all_reduce on the partial tensor and turns an exception into a status code."""
+    from gcc_nmf_amd.distributed import collective_hook
+    assert collective_hook(torch.zeros(4))[:2] == (None, None)               # no process group: single rank, no hook
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_hook_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / ('hook_rank%d.npy' % r)), np.full(1000, 3.0, np.float32))

@@ -49,6 +49,32 @@ def test_pitches_and_workspace_sizes():
     assert lib.gccnmf_istft_ola(0, 3, 1024, 256, 4, 1, 0, 0, 1.0, 1, 0, 0, 0) == 1
 
 
+def test_shared_run_argument_checks_and_workspace_sizes():
+    """gccnmf_klnmf_shared_run / the shard descriptor: sizes and argument checking happen before any HIP call."""
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    Fp, Kp = 528, 1024
+    # column blocks of one [Fp][ld] matrix: R has the matrix's layout, Upart / rowsum_part are per block
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 640, 1024, 31, 20032) == Fp * 20032 + 31 * (Fp * Kp + Kp)
+    # whole padded files back to back
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 64, 0) == 64 * (Fp * 1280 + Fp * Kp + Kp)
+    # ONE file in the plain layout also carries the split-K scratch of the latency path (4 x max(Fp*Np, Fp*Kp) + 4 x Kp)
+    one = Fp * 1280 + Fp * Kp + Kp
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 0) == one + 4 * (Fp * 1280 + Kp)
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 1280) == one + 4 * (Fp * 1280 + Kp)
+    assert lib.gccnmf_klnmf_shared_workspace_floats(513, 1244, 1024, 1) == one + 4 * (Fp * 1280 + Kp) + 2 * Kp
+    assert lib.gccnmf_klnmf_shared_partial_floats(513, 1024) == Fp * Kp + Kp
+    for bad in [(513, 100, 1024, 2, 640), (513, 640, 1024, 3, 1280), (513, 640, 1024, 1, 642), (513, 0, 1024, 1, 0)]:
+        assert lib.gccnmf_klnmf_shared_shard_workspace_floats(*bad) == -1      # ragged block in a batch / blocks beyond ld / pitch % 4 / N = 0
+    arr = (_hip.SharedShard * 1)()
+    assert lib.gccnmf_klnmf_shared_run(arr, 1, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1     # null shard pointers
+    assert lib.gccnmf_klnmf_shared_run(None, 9, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # > GCCNMF_MAX_SHARDS
+    assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
+    assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 2) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
+    assert lib.gccnmf_rccl_comm_init(None, 2, 0, None) == 1 and lib.gccnmf_rccl_allreduce(None, None, 4, None) == 1
+    assert lib.gccnmf_stft_dft(0, 0, 0, 1000, 250, 1, 1, 0, 0, 0, 0) == 1 and lib.gccnmf_dft_workspace_floats(1000, 0, 2) == -1
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
