@@ -875,25 +875,32 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
         const long total = tpf * a.batch, rounds = total / 512;
         // Decided by a cost model in units of one paired round of full tiles = 250 (measured at Kd = 1024: 0.25 ms; everything scales
         // with Kd alike): a partial round of <= 256 full tiles costs 135 (one workgroup alone per CU), a larger one a whole round;
-        // half-height workgroups (130-170 VGPRs, 43 KB of LDS: three per CU) cost 85 up to one per CU, 135 up to two, 190 up to
-        // three; a second launch costs 10 (profiles/r03f_files_sweep.txt).
-        if (gccnmf_tune_tail_split && !gccnmf_trace_buf && a.M > 256) {
+        // half-height workgroups (130-170 VGPRs, 43 KB of LDS: three per CU, 768 per round) cost 85 up to one per CU, 135 up to two,
+        // 190 for three; a second launch costs 10 (profiles/r03g_files_sweep.txt, r03k_files_sweep.txt).
+        if (gccnmf_tune_tail_split == 2 && a.M > 256)                 // experiment: every tile half-height (three workgroups per CU)
+            return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+        if (gccnmf_tune_tail_split && !gccnmf_trace_buf && !a.concurrent && a.M > 256) {
+            // three forms, priced for a launch that has the chip to itself: all full tiles | whole rounds of full tiles + the rest
+            // of the files half-height | everything half-height (768 per round: 32 files 0.389 -> 0.330 ms, 16 files 0.249 -> 0.192)
             auto full_cost = [](long tiles) { const long r = tiles % 512; return (tiles / 512) * 250 + (r == 0 ? 0 : r <= 256 ? 135 : 250); };
-            auto half_cost = [](long halves) { return halves <= 256 ? 85L : halves <= 512 ? 135L : halves <= 768 ? 190L : 1L << 40; };
-            if (rounds == 0) {                                       // less than one round: all of it as half-height tiles?
-                if (half_cost(2 * total) < full_cost(total)) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
-            } else {
-                const int head = (int)(rounds * 512 / tpf);          // whole files that fit the whole rounds
-                const int rest = a.batch - head;
-                if (head >= 8 && rest >= 1 && full_cost(head * tpf) + half_cost(2 * rest * tpf) + 10 < full_cost(total)) {
-                    GemmArgs h = a, t = a;
-                    h.batch = head;
-                    t.batch = rest;
-                    t.file0 = a.file0 + head;
-                    int rc = gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(h, stream);
-                    if (rc) return rc;
-                    return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(t, stream);
-                }
+            auto half_cost = [](long halves) {
+                const long r = halves % 768;
+                return (halves / 768) * 190 + (r == 0 ? 0 : r <= 256 ? 85 : r <= 512 ? 135 : 190);
+            };
+            const long plain = full_cost(total), all_half = half_cost(2 * total);
+            long split = 1L << 40;
+            const int head = (int)(rounds * 512 / tpf);              // whole files that fit the whole rounds
+            const int rest = a.batch - head;
+            if (rounds >= 1 && head >= 8 && rest >= 1 && 2 * rest * tpf <= 768) split = full_cost(head * tpf) + half_cost(2 * rest * tpf) + 10;
+            if (all_half < plain && all_half <= split) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+            if (split < plain) {
+                GemmArgs h = a, t = a;
+                h.batch = head;
+                t.batch = rest;
+                t.file0 = a.file0 + head;
+                int rc = gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(h, stream);
+                if (rc) return rc;
+                return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(t, stream);
             }
         }
     }

@@ -61,6 +61,8 @@ struct GemmArgs {
     int M, N, Kd;              // MFMA output rows, output columns, reduction length
     int a_clamp, b_clamp;      // KC operand: last addressable row; non-KC operand: last addressable float4 start column
     int tiles_m, tiles_n, batch, xcd_affine;
+    int concurrent;            // 1 = this launch shares the chip with launches of another stream (file groups): keep the throughput tile,
+                               //     its partial round runs beside the other group's kernels
     int file0;                 // first file of this launch (a launch over a sub-range of the batch: strides are applied to file0 + index)
     int kparts;                // ring kernel only: > 0 = the `batch` "files" are kparts balanced parts of ONE reduction of Kd (split-K, partial outputs sC apart)
     int exact_div;             // LDS-DMA kernel, EPI_DIV: 1 = IEEE division instead of v_rcp_f32 + one Newton step (tuning key 7)

@@ -47,7 +47,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_ring = value ? 1 : 0;
         return GCCNMF_OK;
     }
-    if (key == 9 && (value == 0 || value == 1)) {
+    if (key == 9 && value >= 0 && value <= 2) {
         gccnmf_tune_tail_split = value;
         return GCCNMF_OK;
     }
@@ -432,7 +432,7 @@ static int launch_wh_div(const NmfGeom& g, const float* V, const float* W, long 
     a.A = W; a.sA = sW; a.lda = g.Kp; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Np - 4;
     a.M = g.Fm; a.N = g.N; a.Kd = g.K;
-    a.batch = batch; a.xcd_affine = xcd;
+    a.batch = batch; a.xcd_affine = xcd & 1; a.concurrent = (xcd >> 1) & 1;
     a.bscale = hscale; a.s_bscale = sScale;
     a.tail_row = g.F - 1;
     a.C = R; a.sC = g.sV; a.ldc = g.ld;
@@ -453,7 +453,7 @@ static int launch_update_h(const NmfGeom& g, const float* W, long sW, const floa
         a.ktailA = W + (long)(g.F - 1) * g.Kp; a.s_ktailA = sW;
         a.ktailB = R + (long)(g.F - 1) * g.ld; a.s_ktailB = g.sV;
     }
-    a.batch = batch; a.xcd_affine = xcd;
+    a.batch = batch; a.xcd_affine = xcd & 1; a.concurrent = (xcd >> 1) & 1;
     a.C = H; a.sC = g.sH; a.ldc = g.ld;
     a.E1 = hscale; a.sE1 = sScale;
     a.E2 = colsumW; a.sE2 = sVec;
@@ -468,7 +468,7 @@ static int launch_rht(const NmfGeom& g, const float* R, const float* H, float* U
     a.A = R; a.sA = g.sV; a.lda = g.ld; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = g.N;
-    a.batch = batch; a.xcd_affine = xcd;
+    a.batch = batch; a.xcd_affine = xcd & 1; a.concurrent = (xcd >> 1) & 1;
     a.tail_row = g.F - 1;
     a.rowsumB = rowsumH; a.s_rowsumB = g.Kp;
     a.C = U; a.sC = g.sU; a.ldc = g.Kp;
@@ -488,7 +488,7 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
     a.A = R; a.sA = g.sV; a.lda = g.ld; a.a_clamp = g.Fp - 1;
     a.B = H; a.sB = g.sH; a.ldb = g.ld; a.b_clamp = g.Kp - 1;
     a.M = g.Fm; a.N = g.K; a.Kd = g.N;
-    a.batch = batch; a.xcd_affine = xcd;
+    a.batch = batch; a.xcd_affine = xcd & 1; a.concurrent = (xcd >> 1) & 1;
     a.tail_row = g.F - 1;
     a.C = W; a.sC = g.sW; a.ldc = g.Kp;
     a.out_colsum = colsumW; a.out_norm = hscale; a.s_out = g.Kp;
@@ -612,7 +612,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
     const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
-    const int xcd = (flags & 1) ? 0 : 1;
+    const int xcd = ((flags & 1) ? 0 : 1) | ((flags & 4) ? 2 : 0);      // bit 1: another file group's launches run beside these
     const int vec_grid = batch * (g.Kp / 16);
     switch (stage) {
         case 0:

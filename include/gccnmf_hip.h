@@ -38,6 +38,8 @@ extern "C" {
 /* flags for gccnmf_klnmf */
 #define GCCNMF_FLAG_NO_XCD_AFFINITY 1   /* plain file-major block order instead of the XCD-affine map */
 #define GCCNMF_FLAG_UNFUSED_W_UPDATE 2   /* R.H^T and the W update/normalisation as two launches (always so when F-1 > 512) */
+#define GCCNMF_FLAG_CONCURRENT_GROUPS 4  /* another file group runs the same call on another stream: keep the throughput tile (a launch
+                                          * that has the chip to itself may run its partial last round, or all of it, on half-height tiles) */
 
 int gccnmf_version(void);
 
@@ -52,8 +54,9 @@ int gccnmf_version(void);
  * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
  * small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
  * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
- * key 9: 1 (default) = the files of a throughput-tile launch's partial last round run as a second launch of half-height tiles
- * (bitwise the same results).  Unknown keys / values: GCCNMF_ERR_ARG. */
+ * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
+ * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout
+ * (bitwise the same results in every form); 0 = always full tiles; 2 = always half-height (experiments).  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */

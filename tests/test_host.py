@@ -70,7 +70,7 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_run(arr, 1, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1     # null shard pointers
     assert lib.gccnmf_klnmf_shared_run(None, 9, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # > GCCNMF_MAX_SHARDS
     assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
-    assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 2) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
+    assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 3) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
     assert lib.gccnmf_rccl_comm_init(None, 2, 0, None) == 1 and lib.gccnmf_rccl_allreduce(None, None, 4, None) == 1
     assert lib.gccnmf_stft_dft(0, 0, 0, 1000, 250, 1, 1, 0, 0, 0, 0) == 1 and lib.gccnmf_dft_workspace_floats(1000, 0, 2) == -1
 
