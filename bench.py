@@ -12,8 +12,10 @@ the rank's batch: samples already resident in HBM -> STFT -> KL-NMF -> GCC-PHAT 
 GCC-NMF masks -> reconstruction -> iSTFT/OLA -> separated waveforms in HBM.  Files are independent,
 so ranks share nothing on the data path (weak scaling, no collective inside the timed region).
 
-Prints ONE JSON line (rank 0).  `roofline` times the dominant kernel live with HIP events on the
-launch stream; `cpu_baseline` times the NumPy oracle (a port of the reference) on one file.
+Prints ONE JSON line (rank 0).  `value` is the bench contract's rate (inputs resident in HBM when the timed region starts);
+`sec8d_host_to_host` is SURVEY 8(d)'s metric (host samples in -> host waveforms out, 8 batches pipelined); `roofline` times the
+dominant kernel live with HIP events on the launch stream; `cpu_baseline` times the NumPy oracle (a port of the reference) on
+one file at the best of a few BLAS thread counts.
 """
 import argparse
 import json
