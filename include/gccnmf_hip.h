@@ -150,7 +150,9 @@ int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, 
  *   W [Fp][Kp] in/out (identical on every rank on entry -> identical on exit), partial: gccnmf_klnmf_shared_partial_floats
  *   floats, vec: 2*Kp floats of scratch.  The shards' partial sums are added in shard order (deterministic).
  * allreduce: sums `count` floats of `buf` (device memory) in place over all ranks, ordered on `stream`; returns 0 on success.
- *   NULL = single rank.  gccnmf_rccl_allreduce below is the RCCL implementation; any other transport (MPI, a host callback that
+ *   NULL = single rank.  Not re-entrant per device: the file groups of a shard that cannot fill the chip run on side streams and
+ *   events the library owns, one set per device (tuning key 8) -- one training at a time per device, like the reference's
+ *   single-threaded caller.  gccnmf_rccl_allreduce below is the RCCL implementation; any other transport (MPI, a host callback that
  *   runs torch.distributed over gloo ...) has the same signature. */
 #define GCCNMF_MAX_SHARDS 8
 typedef struct gccnmf_shared_shard {
