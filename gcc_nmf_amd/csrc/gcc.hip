@@ -93,50 +93,60 @@ __global__ __launch_bounds__(64) void pick_peaks_kernel(const double* __restrict
 }
 
 // P[f][i*Tp + t] = Re(C[f,t] * exp(-j 2 pi f tau_i)) = Cr*cos + Ci*sin, zero in every padded position.
-// grid = (ceil(S*Tp/256), Fp, batch)
+// One thread = four consecutive frames (16-byte loads of Cr / Ci, one 16-byte store).  grid = (ceil(S*Tp/1024), Fp, batch)
 __global__ __launch_bounds__(256) void gcc_steer_kernel(const float* __restrict__ CC, const float* __restrict__ trig,
                                                         const int* __restrict__ tdoa_idx, int F, int Fp, int T, int Tp, int D,
                                                         int Dp, int S, float* __restrict__ P) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int col = 4 * (blockIdx.x * 256 + threadIdx.x);
     const int f = blockIdx.y, b = blockIdx.z;
     if (col >= S * Tp) return;
-    const int i = col / Tp, t = col - i * Tp;
-    float out = 0.f;
+    const int i = col / Tp, t = col - i * Tp;                   // Tp is a multiple of 64: the four frames share the target
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f < F && t < T) {
         int tau = tdoa_idx[(long)b * S + i];
         tau = tau < 0 ? 0 : (tau >= D ? D - 1 : tau);
         const long plane = (long)Fp * Tp;
-        const float cr = CC[(long)b * 2 * plane + (long)f * Tp + t];
-        const float ci = CC[(long)b * 2 * plane + plane + (long)f * Tp + t];
-        const float c = trig[(long)f * Dp + tau], s = trig[((long)Fp + f) * Dp + tau];
-        out = cr * c + ci * s;
+        const float4 cr = *(const float4*)(CC + (long)b * 2 * plane + (long)f * Tp + t);
+        const float4 ci = *(const float4*)(CC + (long)b * 2 * plane + plane + (long)f * Tp + t);
+        const float c = trig[(long)f * Dp + tau], sn = trig[((long)Fp + f) * Dp + tau];
+        out.x = cr.x * c + ci.x * sn;
+        if (t + 1 < T) out.y = cr.y * c + ci.y * sn;
+        if (t + 2 < T) out.z = cr.z * c + ci.z * sn;
+        if (t + 3 < T) out.w = cr.w * c + ci.w * sn;
     }
-    P[((long)b * Fp + f) * ((long)S * Tp) + col] = out;
+    *(float4*)(P + ((long)b * Fp + f) * ((long)S * Tp) + col) = out;
 }
 
 // argmax over targets, first index wins ties, NaN ignored (numpy.nanargmax, gccNMFFunctions.py:138).
-// grid = (ceil(Tp/256), Kp, batch)
+// One thread = four consecutive frames (S 16-byte loads, one 4-byte store).  grid = (ceil(Tp/1024), Kp, batch)
 __global__ __launch_bounds__(256) void gcc_argmax_kernel(const float* __restrict__ scores, int K, int Kp, int T, int Tp, int S,
                                                          unsigned char* __restrict__ argmax) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = 4 * (blockIdx.x * 256 + threadIdx.x);
     const int k = blockIdx.y, b = blockIdx.z;
     if (t >= Tp) return;
-    unsigned char best = 0;
+    unsigned char best[4] = {0, 0, 0, 0};
     if (k < K && t < T) {
         const float* row = scores + ((long)b * Kp + k) * ((long)S * Tp) + t;
-        float bv = 0.f;
-        bool have = false;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        bool have[4] = {false, false, false, false};
         for (int i = 0; i < S; ++i) {
-            const float v = row[(long)i * Tp];
-            if (v != v) continue;
-            if (!have || v > bv) {
-                bv = v;
-                best = (unsigned char)i;
-                have = true;
+            const float4 v4 = *(const float4*)(row + (long)i * Tp);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (v[j] != v[j]) continue;
+                if (!have[j] || v[j] > bv[j]) {
+                    bv[j] = v[j];
+                    best[j] = (unsigned char)i;
+                    have[j] = true;
+                }
             }
         }
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (t + j >= T) best[j] = 0;                          // padded frames stay 0
     }
-    argmax[((long)b * Kp + k) * Tp + t] = best;
+    *(uchar4*)(argmax + ((long)b * Kp + k) * Tp + t) = make_uchar4(best[0], best[1], best[2], best[3]);
 }
 
 // PHAT coherence X0*conj(X1)/|X0|/|X1| from an existing spectrogram (runGCCNMF.py:44); the pipeline gets
@@ -165,25 +175,36 @@ __global__ __launch_bounds__(256) void gcc_coherence_kernel(const float2* __rest
 }
 
 // Hm[k][(i*2+c)*Tp + t] = H[k][c*T + t] if argmax[k][t] == i else 0 (H_c * M_i, gccNMFFunctions.py:150).
-// grid = (ceil(2*S*Tp/256), Kp, batch)
+// One thread = four consecutive frames of one (target, channel) block: one 16-byte store (the write is 4/5 of this kernel's traffic:
+// 1 GB per 64-file step), the arg-max as one 4-byte load; H_c starts at column c*T, which is only 4-byte aligned: scalar loads (L2).
+// grid = (ceil(2*S*Tp/1024), Kp, batch)
 __global__ __launch_bounds__(256) void gcc_masked_h_kernel(const float* __restrict__ H, const unsigned char* __restrict__ argmax,
                                                            const float* __restrict__ masks, int K, int Kp, int T, int Tp, int Np,
                                                            int S, float* __restrict__ Hm) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int col = 4 * (blockIdx.x * 256 + threadIdx.x);
     const int k = blockIdx.y, b = blockIdx.z;
     const int ncol = 2 * S * Tp;
     if (col >= ncol) return;
-    const int ic = col / Tp, t = col - ic * Tp;
+    const int ic = col / Tp, t = col - ic * Tp;                 // Tp is a multiple of 64: the four frames share (target, channel)
     const int i = ic >> 1, c = ic & 1;
-    float out = 0.f;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < K && t < T) {
-        const float h = H[((long)b * Kp + k) * Np + c * T + t];
-        if (masks)   // arbitrary (soft) masks [batch][S][Kp][Tp]: coefficients * targetCoefficientMask
-            out = h * masks[(((long)b * S + i) * Kp + k) * Tp + t];
-        else if (argmax[((long)b * Kp + k) * Tp + t] == i)
-            out = h;
+        const float* h = H + ((long)b * Kp + k) * Np + c * T + t;
+        float4 m;
+        if (masks) {   // arbitrary (soft) masks [batch][S][Kp][Tp]: coefficients * targetCoefficientMask
+            m = *(const float4*)(masks + (((long)b * S + i) * Kp + k) * Tp + t);
+        } else {
+            const uchar4 a = *(const uchar4*)(argmax + ((long)b * Kp + k) * Tp + t);
+            m = make_float4(a.x == i ? 1.f : 0.f, a.y == i ? 1.f : 0.f, a.z == i ? 1.f : 0.f, a.w == i ? 1.f : 0.f);
+        }
+        // (h * 1.0f and h * 0.0f are h and +-0: the product form IS the select for finite h, and NaN / Inf coefficients propagate as in
+        // the reference's H * mask)
+        out.x = h[0] * m.x;
+        if (t + 1 < T) out.y = h[1] * m.y;
+        if (t + 2 < T) out.z = h[2] * m.z;
+        if (t + 3 < T) out.w = h[3] * m.w;
     }
-    Hm[((long)b * Kp + k) * (long)ncol + col] = out;
+    *(float4*)(Hm + ((long)b * Kp + k) * (long)ncol + col) = out;
 }
 
 // C [batch][M][ldc] = A . B with both operands stored [reduction][.] (A(i,kk) = A[kk*lda + i], B(kk,j) = B[kk*ldb + j]), plain store:
@@ -252,7 +273,7 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
     const int Dp = gccnmf_round_up(D, 64);
     const int ncol = S * p.Tp;
     float* P = workspace;
-    hipLaunchKernelGGL(gcc_steer_kernel, dim3(gccnmf_ceil_div(ncol, 256), p.Fp, batch), dim3(256), 0, s, CC, trig, tdoa_idx, F,
+    hipLaunchKernelGGL(gcc_steer_kernel, dim3(gccnmf_ceil_div(ncol, 1024), p.Fp, batch), dim3(256), 0, s, CC, trig, tdoa_idx, F,
                        p.Fp, T, p.Tp, D, Dp, S, P);
     GCCNMF_CHECK_LAUNCH();
     GemmArgs a = {};
@@ -273,7 +294,7 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
                         : gccnmf_launch_gemm<1, 4, false, false, EPI_STORE, false>(a, s);
     if (rc) return rc;
     if (argmax) {
-        hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 256), p.Kp, batch), dim3(256), 0, s, scores, K, p.Kp, T,
+        hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 1024), p.Kp, batch), dim3(256), 0, s, scores, K, p.Kp, T,
                            p.Tp, S, argmax);
         GCCNMF_CHECK_LAUNCH();
     }
@@ -283,7 +304,7 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
 int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, unsigned char* argmax, void* stream) {
     if (!scores || !argmax || K < 1 || T < 1 || S < 1 || S > 255 || batch < 1) return GCCNMF_ERR_ARG;
     GccNmfPitches p = gccnmf_make_pitches(2, T, K);
-    hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 256), p.Kp, batch), dim3(256), 0, (hipStream_t)stream, scores,
+    hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 1024), p.Kp, batch), dim3(256), 0, (hipStream_t)stream, scores,
                        K, p.Kp, T, p.Tp, S, argmax);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
@@ -312,7 +333,7 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
     GccNmfPitches p = gccnmf_make_pitches(F, T, K);
     const int ncol = 2 * S * p.Tp;
     float* Hm = workspace;
-    hipLaunchKernelGGL(gcc_masked_h_kernel, dim3(gccnmf_ceil_div(ncol, 256), p.Kp, batch), dim3(256), 0, s, H, argmax, masks, K, p.Kp,
+    hipLaunchKernelGGL(gcc_masked_h_kernel, dim3(gccnmf_ceil_div(ncol, 1024), p.Kp, batch), dim3(256), 0, s, H, argmax, masks, K, p.Kp,
                        T, p.Tp, p.Np, S, Hm);
     GCCNMF_CHECK_LAUNCH();
     const bool tail = (F % 128) == 1;
