@@ -111,6 +111,11 @@ def lib():
             raise HipLibraryError('%s does not export %s (stale build? re-run make -C gcc_nmf_amd/csrc)' % (LIB_PATH, name))
         fn.restype = restype
         fn.argtypes = argtypes
+    # A/B runs without code changes: GCCNMF_TUNE="9=2,8=1" applies gccnmf_set_tuning(key, value) pairs at load time
+    for kv in filter(None, os.environ.get('GCCNMF_TUNE', '').split(',')):
+        key, value = [int(v) for v in kv.split('=')]
+        if handle.gccnmf_set_tuning(key, value) != 0:
+            raise HipLibraryError('GCCNMF_TUNE: gccnmf_set_tuning(%d, %d) was rejected' % (key, value))
     _lib = handle
     return _lib
 
