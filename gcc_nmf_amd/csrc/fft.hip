@@ -12,6 +12,9 @@
 //   forward : z = w*(xL + j xR);  F_L[k] = (Z[k]+conj(Z[N-k]))/2,  F_R[k] = (Z[k]-conj(Z[N-k]))/(2j)
 //   inverse : Z = F_a + j F_b (both Hermitian-extended)  ->  ifft(Z) = y_a + j y_b
 #include "fft_core.h"
+#ifndef FFT_ABL
+#define FFT_ABL 0     // build-time timing experiments (results invalid): 1 = no butterfly stages, 2 = no output stage (STFT kernel)
+#endif
 
 // grid = batch * ceil(T / TB); dynamic LDS = (TB*(N+ZPAD) + N/2) float2.
 // PCM16 = true: x points at interleaved int16 frames [n][2] (a wav file's data chunk); the int16 -> float32 / 32768
@@ -50,7 +53,12 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
         z[tb * zstride + bitrev(n, logN)] = v;
     }
     __syncthreads();
+#if !(FFT_ABL & 1)
     fft_stages<false, TB>(z, tw, N, logN, zstride);
+#endif
+#if FFT_ABL & 2
+    if (z[threadIdx.x].x != 123.456f) return;       // timing experiment: no output stage
+#endif
 
     const long plane = (long)Fp * Tp;
     float2* Xb = X + (long)b * 2 * plane;
