@@ -18,18 +18,17 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
 // The butterflies of a stage are independent, so a thread takes them FFT_UN at a time: all LDS loads of a batch are issued before
 // the first store (the compiler cannot move a load across a store into the same array itself; one butterfly per round trip made a
 // stage 16 dependent LDS latencies long: 0.24 of the STFT's 0.60 ms).  Same operations per butterfly in the same order: same bits.
-#define FFT_UN 8
-template <bool INVERSE, int TB = FFT_TB>
-__device__ __forceinline__ void fft_stages(float2* z, const float2* tw, int N, int logN, int zstride) {
+template <bool INVERSE, int TB, int UN>
+__device__ __forceinline__ void fft_stages_un(float2* z, const float2* tw, int N, int logN, int zstride) {
     const int half_n = N >> 1, total = TB * half_n;
     for (int s = 1; s <= logN; ++s) {
         const int half = 1 << (s - 1);
         const int tw_step = N >> s;
-        for (int base = threadIdx.x; base < total; base += FFT_NT * FFT_UN) {
-            float2 u[FFT_UN], v[FFT_UN], w[FFT_UN];
-            int i0[FFT_UN];
+        for (int base = threadIdx.x; base < total; base += FFT_NT * UN) {
+            float2 u[UN], v[UN], w[UN];
+            int i0[UN];
 #pragma unroll
-            for (int j = 0; j < FFT_UN; ++j) {
+            for (int j = 0; j < UN; ++j) {
                 const int idx = base + j * FFT_NT;
                 if (idx < total) {
                     const int tb = idx >> (logN - 1), bf = idx & (half_n - 1);
@@ -41,7 +40,7 @@ __device__ __forceinline__ void fft_stages(float2* z, const float2* tw, int N, i
                 }
             }
 #pragma unroll
-            for (int j = 0; j < FFT_UN; ++j) {
+            for (int j = 0; j < UN; ++j) {
                 const int idx = base + j * FFT_NT;
                 if (idx < total) {
                     float2 wj = w[j];
@@ -54,6 +53,14 @@ __device__ __forceinline__ void fft_stages(float2* z, const float2* tw, int N, i
         }
         __syncthreads();
     }
+}
+
+// (eight at a time when a thread has at least four butterflies per stage -- the offline kernels: 16; one at a time otherwise -- the
+// streaming processor's single frame: one butterfly per thread, where the eight predicated slots cost 20 us per block)
+template <bool INVERSE, int TB = FFT_TB>
+__device__ __forceinline__ void fft_stages(float2* z, const float2* tw, int N, int logN, int zstride) {
+    if (TB * (N >> 1) >= 4 * FFT_NT) fft_stages_un<INVERSE, TB, 8>(z, tw, N, logN, zstride);
+    else fft_stages_un<INVERSE, TB, 1>(z, tw, N, logN, zstride);
 }
 
 __device__ __forceinline__ int bitrev(int n, int logN) { return (int)(__brev((unsigned)n) >> (32 - logN)); }
