@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         if (piece >= GEMM_DMA_SKIP_FROM) return;                    // timing experiment (results invalid): fewer pieces per k-tile
 #endif
         if (piece < NA) {
-            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece < NA ? piece : 0], lds0 + 4 * (buf * SBUF + (wave * NA + piece) * 256));
+            gemm_dma16(A + (A_KC ? (long)kt * BK : (long)kt * BK * p.lda), offA[piece], lds0 + 4 * (buf * SBUF + (wave * NA + piece) * 256));
         } else if (piece == NA) {
             gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb), offB, lds0 + 4 * (buf * SBUF + SA + wave * 256));
         } else {

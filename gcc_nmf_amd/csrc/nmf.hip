@@ -861,7 +861,7 @@ static int shared_finish(const SharedShard* sh, int n, float* hscale, int K, hip
 }
 
 // the four-call protocol's workspace: one default-layout shard's scratch | colsumW [Kp] | hscale [Kp]
-static float* legacy_vec(float* ws, const SharedShard& sh) {
+static float* legacy_vec(const SharedShard& sh) {
     return sh.parts ? sh.rowsum_parts + GCCNMF_SPLITS * (long)sh.g.Kp : sh.rowsum_part + (long)sh.batch * sh.g.Kp;
 }
 
@@ -886,7 +886,7 @@ long gccnmf_klnmf_shared_partial_floats(int F, int K) {
 int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, int K, int batch, void* stream) {
     if (!W || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
-    float* vec = legacy_vec(workspace, sh);
+    float* vec = legacy_vec(sh);
     return shared_begin(&sh, 1, W, vec, vec + sh.g.Kp, F, K, (hipStream_t)stream);
 }
 
@@ -894,21 +894,21 @@ int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* 
                                int K, int batch, float sparsity_alpha, float epsilon, void* stream) {
     if (!V || !W || !H || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(V, H, workspace, F, N, K, batch, 0);
-    float* vec = legacy_vec(workspace, sh);
+    float* vec = legacy_vec(sh);
     return shared_step_a_all(&sh, 1, W, vec, vec + sh.g.Kp, partial, sparsity_alpha, epsilon, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch, void* stream) {
     if (!W || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
-    float* vec = legacy_vec(workspace, sh);
+    float* vec = legacy_vec(sh);
     return shared_step_b(W, partial, vec, vec + sh.g.Kp, F, K, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream) {
     if (!H || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, H, workspace, F, N, K, batch, 0);
-    float* vec = legacy_vec(workspace, sh);
+    float* vec = legacy_vec(sh);
     return shared_finish(&sh, 1, vec + sh.g.Kp, K, (hipStream_t)stream);
 }
 
