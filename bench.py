@@ -490,6 +490,7 @@ def main():
             out['cpu_baseline']['reference_on_gpu_box'] = {
                 'frames_per_s': r0['frames_per_s'], 'nmf_only_frames_per_s': r0['nmf_only_frames_per_s'], 'host_cpus': r0['host_cpus'],
                 'blas_threads': max(t['num_threads'] for t in r0['thread_pools']) if r0.get('thread_pools') else None,
+                'best_frames_per_s': r0.get('best_frames_per_s'), 'best_blas_threads': r0.get('best_blas_threads'),
                 'source': 'profiles/reference_cpu_on_gpu_box.json (same file 0, same parameters; recorded once, not re-timed here)'}
         y0 = e.y[0].cpu().numpy()
         out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))
