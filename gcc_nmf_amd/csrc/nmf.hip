@@ -28,7 +28,7 @@ long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
 extern "C" {
-int gccnmf_version(void) { return 101; }
+int gccnmf_version(void) { return 103; }   // round 3: shared run + RCCL hook, any-n_fft DFT path, tile-layout cost model
 
 int gccnmf_set_tuning(int key, int value) {
     if (key == 1) {
