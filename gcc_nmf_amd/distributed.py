@@ -65,7 +65,7 @@ _rccl_comms = {}
 def _rccl_comm(group, device):
     """The library-owned RCCL communicator of (group, device), or None when RCCL cannot be used on EVERY rank."""
     import ctypes
-    key = (id(group) if group is not None else 0, torch.device(device).index)
+    key = (group if group is not None else 'world', torch.device(device).index)      # the group object itself: no id() reuse after a destroy
     if key in _rccl_comms:
         return _rccl_comms[key]
     lib = _hip.lib()
