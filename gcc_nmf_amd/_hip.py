@@ -19,6 +19,18 @@ class SharedShard(ctypes.Structure):
     _fields_ = [('V', c_void_p), ('H', c_void_p), ('workspace', c_void_p), ('N', c_int), ('batch', c_int), ('ld', c_int)]
 
 
+class DirectGemm(ctypes.Structure):
+    """gccnmf_direct_gemm (include/gccnmf_hip.h): descriptor of one latency-path GEMM (csrc/direct.hip)"""
+    _fields_ = [('A', c_void_p), ('B', c_void_p), ('sA', c_long), ('sB', c_long), ('lda', c_int), ('ldb', c_int),
+                ('M', c_int), ('N', c_int), ('Kd', c_int), ('batch', c_int),
+                ('bscale', c_void_p), ('s_bscale', c_long), ('tailA', c_void_p), ('s_tailA', c_long), ('tail_row', c_int),
+                ('rowsumB', c_void_p), ('s_rowsumB', c_long), ('C', c_void_p), ('sC', c_long), ('ldc', c_int),
+                ('Ct', c_void_p), ('sCt', c_long), ('ldct', c_int), ('E0', c_void_p), ('sE0', c_long), ('lde0', c_int),
+                ('E1', c_void_p), ('sE1', c_long), ('E2', c_void_p), ('sE2', c_long), ('ktailA', c_void_p), ('ktailB', c_void_p),
+                ('s_ktailA', c_long), ('s_ktailB', c_long), ('alpha', c_float), ('eps', c_float),
+                ('tiles_m', c_int), ('tiles_n', c_int), ('xc', c_int), ('sm', c_int), ('sn', c_int)]
+
+
 # gccnmf_allreduce_fn: int (*)(void* ctx, float* buf, long count, void* stream)
 RCCL_UNIQUE_ID_BYTES = 128
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_long, c_void_p)
@@ -77,6 +89,7 @@ SIGNATURES = {
     'gccnmf_ola_frames_halo': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'gccnmf_rt_process_block': (c_int, [c_void_p] * 19 + [c_int] * 13 + [c_void_p]),
     'gccnmf_rt_process_block_ll': (c_int, [c_void_p] * 23 + [c_int] * 15 + [c_void_p]),
+    'gccnmf_gemm_direct': (c_int, [ctypes.POINTER(DirectGemm), c_int, c_int, c_void_p]),
     'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),
     'gccnmf_debug_mfma_peak': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'gccnmf_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1,0 +1,28 @@
+// Latency-path GEMM (one mixture alone, a handful of files): interface of csrc/direct.hip.
+//
+//   C[m][n] (+ fused element-wise work) = sum_r A[r][m] * B[r][n]          r < Kd, m < M, n < N
+//
+// BOTH operands are reduction-major ("r-major": one reduction index per row, the output index contiguous).  That is the layout in
+// which a 16x16x4 MFMA operand can be fetched from global memory straight into registers with fully coalesced 16-byte loads
+// (a lane group of 16 reads 256 contiguous bytes of one reduction row), so the kernel needs no LDS staging, no LDS-DMA and no
+// barrier in its main loop.  The KL-NMF driver keeps transposed copies (Wt, Ht, Rt) so that each of its four GEMMs has this form.
+#pragma once
+#include "common.h"
+#include "../../include/gccnmf_hip.h"
+
+enum DirectEpilogue {
+    DEPI_STORE = 0,   // C = acc                                             (U = R.H^T; + row sums of B, + tail row)
+    DEPI_DIV = 1,     // C = E0 / acc                                        (R = V / (W.H), gccNMFFunctions.py:76 inner)
+    DEPI_DIVT = 2,    // Ct[n][m] = E0[m][n] / acc  (transposed output only; the tail row goes to C and Ct)    (:77 inner)
+    DEPI_UPDH = 3     // C = (C*E1[m]) * ((acc + ktailA[m]*ktailB[n]) / (E2[m] + alpha + eps)), also stored transposed into Ct   (:76)
+};
+
+// the argument block is the public descriptor (include/gccnmf_hip.h: gccnmf_direct_gemm documents every field)
+typedef gccnmf_direct_gemm DirectArgs;
+
+// epi: DirectEpilogue.  tile: 0 = chosen by the cost model, 1.. = index into the tile table (experiments).  Returns a GCCNMF_* status.
+int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream);
+
+// out[c][r] = in[r][c] for r < rows, c < cols (batched; strides in floats) -- the transposed copies the direct path starts from
+int gccnmf_transpose_launch(const float* in, long s_in, int ld_in, float* out, long s_out, int ld_out, int rows, int cols, int batch,
+                            hipStream_t stream);

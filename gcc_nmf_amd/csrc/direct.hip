@@ -1,0 +1,473 @@
+// Latency-path GEMM for gfx950: operands straight from global memory into MFMA registers, the reduction split over the
+// waves of a workgroup.  Used where a launch cannot fill the chip with throughput tiles: one mixture alone (the shape behind the
+// reference's own function names: performKLNMF(V (513, 1244), 1024, 100, 0), gccNMF/gccNMFFunctions.py:69-83), a handful of files.
+//
+// Why this form.  A launch over one file is as long as ONE workgroup's dependent chain, so the way to make it short is (i) every
+// SIMD of the chip busy, (ii) with equal work, (iii) without partial results crossing workgroups.  A 513 x 1244 x 1024 product is
+// 640 blocks of 32 x 32 -- on 1024 SIMDs that is either 62 % of the chip (one block per wave) or a split of the reduction ACROSS
+// workgroups (rounds 2-3: three partial products through HBM plus two combine launches per W.H, 22.6 us against an MFMA floor of
+// 10).  Here the output is cut into exactly-one-round tiles of 16 x 16 blocks instead (32 x 80 for W.H: 16 x 16 = 256 workgroups),
+// and the reduction is split INSIDE the workgroup: wave w multiplies the 16-deep chunks w, w+4, w+8 ... of the reduction into its own
+// copy of the whole tile's accumulators, and the four copies are added in wave order through LDS at the end (deterministic).
+// No operand is shared between waves, so there is nothing to stage: with both operands reduction-major (direct.h) lane (c, g) of a
+// wave loads 16 bytes at row 4g + e, column 4c of the tile -- 256 contiguous bytes per lane group -- and the four floats are the
+// B (or A) values of four 16 x 16 blocks whose columns interleave (block j owns columns 4c + j).  One chunk of a 32 x 80 tile is
+// 12 load instructions for 40 MFMAs (v_mfma_f32_16x16x4_f32, 32 cycles each, 10 independent accumulators): no LDS, no LDS-DMA
+// issue cost, no barrier, no fragment waits in the loop; the next chunk's loads are in flight under the current chunk's MFMAs.
+//
+// Numerics: exact f32 like every other GEMM of the path (k-ordered fmaf chains per wave, then ((p0 + p1) + p2) + p3).
+#include <atomic>
+#include <type_traits>
+#include "direct.h"
+
+#define DIRECT_MAX_DEVICES 64
+extern int gccnmf_tune_ablate;
+
+typedef float df32x4 __attribute__((ext_vector_type(4)));
+typedef float df32x2 __attribute__((ext_vector_type(2)));
+
+template <int W> struct DVec;
+template <> struct DVec<1> { typedef float type; };
+template <> struct DVec<2> { typedef df32x2 type; };
+template <> struct DVec<4> { typedef df32x4 type; };
+__device__ __forceinline__ float dget(float v, int) { return v; }
+__device__ __forceinline__ float dget(df32x2 v, int j) { return v[j]; }
+__device__ __forceinline__ float dget(df32x4 v, int j) { return v[j]; }
+
+// Operand loads are buffer loads: wave-uniform descriptor (SGPRs) + constant per-lane byte offset (voffset) + the chunk's byte offset
+// (soffset, an SGPR) -- no per-load 64-bit address arithmetic on the VALU, and loads the compiler counts in its vmcnt bookkeeping.
+typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned du32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t direct_rsrc(const float* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;      // uniformity made provable: the halves go through readfirstlane
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+template <int W> struct DLoad;
+template <> struct DLoad<1> {
+    static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned s) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, v, s, 0));
+    }
+};
+template <> struct DLoad<2> {
+    static __device__ __forceinline__ df32x2 ld(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned s) {
+        return __builtin_bit_cast(df32x2, __builtin_amdgcn_raw_buffer_load_b64(r, v, s, 0));
+    }
+};
+template <> struct DLoad<4> {
+    static __device__ __forceinline__ df32x4 ld(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned s) {
+        return __builtin_bit_cast(df32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v, s, 0));
+    }
+};
+
+// One 16-deep chunk of both operands in registers: step e (four MFMA steps per chunk) multiplies reduction index 4g + e of the chunk
+// in lane group g = lane / 16.
+template <int MB, int NB>
+struct DirectFrag {
+    static constexpr int G4 = NB / 4, REM = NB % 4;
+    typename DVec<MB>::type a[4];
+    df32x4 b4[4][G4 ? G4 : 1];
+    typename DVec<REM ? REM : 1>::type br[4];
+    df32x4 sc, tl;                                // lazy scale of B / tail-row values of A for reduction indexes 4g .. 4g + 3
+};
+
+template <int MB, int NB, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectArgs p) {
+    static_assert(MB == 1 || MB == 2 || MB == 4, "rows of a tile: 16, 32 or 64");
+    static_assert(NB % 4 != 3, "column groups: float4s plus one float2 or float");
+    constexpr int TR = 16 * MB, TC = 16 * NB;
+    constexpr int G4 = NB / 4, REM = NB % 4;
+    constexpr int P = TC + 4;                                     // pitch of a partial tile in LDS
+    constexpr int PT = TR + 1;                                    // pitch of the transposed image
+    constexpr int NT = 64 * NW;
+    constexpr int C4 = TC / 4, ITEMS = (TR * C4 + NT - 1) / NT;   // float4 outputs per thread
+    constexpr bool TRANSPOSED = EPI == DEPI_DIVT || EPI == DEPI_UPDH;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* const s_part = dsm;                                    // [NW][TR][P]
+    float* const s_t = s_part + NW * TR * P;                      // [TC][PT]
+    float* const s_side = s_t + TC * PT;                          // [2][NW][TC]
+
+    // block -> (file, tm, tn): blocks b, b + 8, ... run on XCD b % 8 (observed, for speed only); XCD x owns the sub-grid
+    // (x / xc, x % xc) of sm x sn tiles, so its L2 holds sm row panels of A and sn column panels of B
+    const int per_file = 8 * p.sm * p.sn;
+    const int file = blockIdx.x / per_file, rem = blockIdx.x - file * per_file;
+    const int xcd = rem & 7, idx = rem >> 3;
+    const int tm = (xcd / p.xc) * p.sm + idx / p.sn, tn = (xcd % p.xc) * p.sn + idx % p.sn;
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int m0 = tm * TR, n0 = tn * TC;
+    const float* __restrict__ A = p.A + file * p.sA;
+    const float* __restrict__ B = p.B + file * p.sB;
+    const int nchunks = (p.Kd + 15) >> 4;
+    const int niter = nchunks > wave ? (nchunks - wave + NW - 1) / NW : 0;
+
+    // per-lane byte offsets inside a chunk (columns past the pitch are clamped: they belong to outputs that are never stored)
+    unsigned offA[4], offB[4][G4 ? G4 : 1], offR[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        offA[e] = 4u * (unsigned)(r * p.lda + min(m0 + MB * c, p.lda - MB));
+#pragma unroll
+        for (int q = 0; q < G4; ++q) offB[e][q] = 4u * (unsigned)(r * p.ldb + min(n0 + 64 * q + 4 * c, p.ldb - 4));
+        offR[e] = REM ? 4u * (unsigned)(r * p.ldb + min(n0 + 64 * G4 + REM * c, p.ldb - REM)) : 0u;
+    }
+    const bool side = tm == 0 && (p.tailA != nullptr || p.rowsumB != nullptr) && EPI != DEPI_UPDH;
+    // (no tail row: the loop still runs its FMAs on some valid memory, the result is dropped)
+    const float* __restrict__ tailv = p.tailA ? p.tailA + file * p.s_tailA : B;
+    const float* __restrict__ scalev = p.bscale ? p.bscale + file * p.s_bscale : B;
+
+    df32x4 acc[MB][NB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[j][nb] = df32x4{0.f, 0.f, 0.f, 0.f};
+    float tacc[NB], racc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) tacc[nb] = racc[nb] = 0.f;
+
+    typedef DirectFrag<MB, NB> Frag;
+    // every load is unconditional (a conditional one would make the compiler drain the queue at the join): past the end the last
+    // chunk is fetched again and never used
+    const unsigned chunkA = 64u * (unsigned)p.lda, chunkB = 64u * (unsigned)p.ldb;      // bytes per 16-row chunk
+    const __amdgpu_buffer_rsrc_t rA = direct_rsrc(A, (unsigned)nchunks * chunkA), rB = direct_rsrc(B, (unsigned)nchunks * chunkB);
+    const __amdgpu_buffer_rsrc_t rS = direct_rsrc(scalev, 64u * (unsigned)nchunks), rT = direct_rsrc(tailv, 64u * (unsigned)nchunks);
+    auto load = [&](auto side_c, auto sc_c, Frag& f, int ch) {
+        constexpr bool SIDE = decltype(side_c)::value, SC = decltype(sc_c)::value;
+        const unsigned chu = (unsigned)__builtin_amdgcn_readfirstlane(min(ch, nchunks - 1));
+        const unsigned sa = chu * chunkA, sb = chu * chunkB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f.a[e] = DLoad<MB>::ld(rA, offA[e], sa);
+#pragma unroll
+            for (int q = 0; q < G4; ++q) f.b4[e][q] = DLoad<4>::ld(rB, offB[e][q], sb);
+            if (REM) f.br[e] = DLoad<REM ? REM : 1>::ld(rB, offR[e], sb);
+        }
+        if (SC) f.sc = DLoad<4>::ld(rS, 16u * (unsigned)g, 64u * chu);
+        if (SIDE) f.tl = DLoad<4>::ld(rT, 16u * (unsigned)g, 64u * chu);
+    };
+    auto compute = [&](auto side_c, auto sc_c, const Frag& f) {
+        constexpr bool SIDE = decltype(side_c)::value, SC = decltype(sc_c)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bv[nb] = nb < 4 * G4 ? f.b4[e][nb < 4 * G4 ? nb / 4 : 0][nb & 3] : dget(f.br[e], nb < 4 * G4 ? 0 : nb - 4 * G4);
+                if (SC) bv[nb] *= f.sc[e];                         // fl(H * s), as every other K1 does
+            }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const float av = dget(f.a[e], j);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[j][nb], 0, 0, 0);
+            }
+            if (SIDE) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    tacc[nb] = fmaf(f.tl[e], bv[nb], tacc[nb]);
+                    racc[nb] += bv[nb];
+                }
+            }
+        }
+    };
+    auto main_loop = [&](auto side_c, auto sc_c) {
+        Frag f0, f1;
+        load(side_c, sc_c, f0, wave);
+        // One scheduling region per chunk: the next chunk's loads dealt out between this chunk's MFMAs (one load per MPL MFMAs), so the
+        // memory pipeline takes them at its own pace while the matrix pipe stays busy.  Left alone, the scheduler sinks every load
+        // to just before its first use to save registers, and the loop waits for a full memory round trip per chunk.
+        constexpr int NLOADS = 4 * (1 + G4 + (REM ? 1 : 0)) + (decltype(side_c)::value ? 1 : 0) + (decltype(sc_c)::value ? 1 : 0);
+        constexpr int NMFMA = 16 * MB * NB / 4;
+        constexpr int MPL = NMFMA / NLOADS > 0 ? NMFMA / NLOADS : 1;
+        auto interleave = [&]() {
+#pragma unroll
+            for (int i = 0; i < NLOADS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        };
+        int it = 0;
+        for (; it + 1 < niter; it += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            load(side_c, sc_c, f1, wave + (it + 1) * NW);
+            compute(side_c, sc_c, f0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            load(side_c, sc_c, f0, wave + (it + 2) * NW);
+            compute(side_c, sc_c, f1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it < niter) compute(side_c, sc_c, f0);        // odd count: the last chunk is already in f0
+    };
+    // loop copies, chosen once per workgroup: with / without the side work of the row-0 tiles, with / without the lazy-scale multiplies
+    if constexpr (EPI == DEPI_UPDH) {
+        main_loop(std::false_type{}, std::false_type{});
+    } else if constexpr (EPI == DEPI_DIV) {
+        if (p.bscale != nullptr) {
+            if (side) main_loop(std::true_type{}, std::true_type{});
+            else main_loop(std::false_type{}, std::true_type{});
+        } else {
+            if (side) main_loop(std::true_type{}, std::false_type{});
+            else main_loop(std::false_type{}, std::false_type{});
+        }
+    } else {
+        if (side) main_loop(std::true_type{}, std::false_type{});
+        else main_loop(std::false_type{}, std::false_type{});
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------------
+    // what the element-wise part needs from global memory is requested before the partial tiles are exchanged
+    const long fC = file * p.sC;
+    df32x4 e0[ITEMS];                               // DIV / DIVT: V; UPDH: the old H
+    df32x4 kb[ITEMS];
+    float rsc[ITEMS], rrd[ITEMS], rka[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int id = tid + it * NT;
+        const int row = id / C4, cq = id - row * C4;
+        const int grow = min(m0 + row, p.M - 1), gcol = min(n0 + 4 * cq, ((p.N - 1) & ~3));
+        e0[it] = df32x4{1.f, 1.f, 1.f, 1.f};
+        kb[it] = df32x4{0.f, 0.f, 0.f, 0.f};
+        rsc[it] = 1.f; rrd[it] = 1.f; rka[it] = 0.f;
+        if (EPI == DEPI_DIV || EPI == DEPI_DIVT) e0[it] = *(const df32x4*)(p.E0 + file * p.sE0 + (long)grow * p.lde0 + gcol);
+        if (EPI == DEPI_UPDH) {
+            e0[it] = *(const df32x4*)(p.C + fC + (long)grow * p.ldc + gcol);
+            if (p.E1) rsc[it] = p.E1[file * p.sE1 + grow];
+            rrd[it] = 1.0f / (p.E2[file * p.sE2 + grow] + p.alpha + p.eps);
+            if (p.ktailA) {
+                rka[it] = p.ktailA[file * p.s_ktailA + grow];
+                kb[it] = *(const df32x4*)(p.ktailB + file * p.s_ktailB + gcol);
+            }
+        }
+    }
+
+    // the wave's copy of the tile -> LDS: accumulator register i of block (j, nb) is row MB * (4g + i) + j, column 4c + (nb % 4) of
+    // column group nb / 4 (one 16-byte store per group)
+    {
+        float* mine = s_part + wave * (TR * P);
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* rowp = mine + (MB * (4 * g + i) + j) * P;
+#pragma unroll
+                for (int q = 0; q < G4; ++q)
+                    *(df32x4*)(rowp + 64 * q + 4 * c) = df32x4{acc[j][4 * q][i], acc[j][4 * q + 1][i], acc[j][4 * q + 2][i], acc[j][4 * q + 3][i]};
+                if (REM == 1) rowp[64 * G4 + c] = acc[j][4 * G4][i];
+                if (REM == 2) *(df32x2*)(rowp + 64 * G4 + 2 * c) = df32x2{acc[j][4 * G4][i], acc[j][4 * G4 + 1][i]};
+            }
+    }
+    if (side) {          // lane groups hold disjoint reduction indexes of the same columns
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float t = tacc[nb], r = racc[nb];
+            t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+            r += __shfl_xor(r, 16); r += __shfl_xor(r, 32);
+            const int lc = nb < 4 * G4 ? 64 * (nb / 4) + 4 * c + (nb & 3) : 64 * G4 + REM * c + (nb - 4 * G4);
+            if (g == 0) {
+                s_side[wave * TC + lc] = t;
+                s_side[(NW + wave) * TC + lc] = r;
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int id = tid + it * NT;
+        if (id < TR * C4) {
+            const int row = id / C4, cq = id - row * C4;
+            const int grow = m0 + row, gcol = n0 + 4 * cq;
+            df32x4 s = *(const df32x4*)(s_part + row * P + 4 * cq);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += *(const df32x4*)(s_part + w * (TR * P) + row * P + 4 * cq);
+            df32x4 o;
+            if (EPI == DEPI_STORE) o = s;
+            if (EPI == DEPI_DIV || EPI == DEPI_DIVT) o = df32x4{e0[it].x / s.x, e0[it].y / s.y, e0[it].z / s.z, e0[it].w / s.w};
+            if (EPI == DEPI_UPDH) {
+                const float sc = rsc[it], rd = rrd[it], ka = rka[it];
+                o = df32x4{(e0[it].x * sc) * (fmaf(ka, kb[it].x, s.x) * rd), (e0[it].y * sc) * (fmaf(ka, kb[it].y, s.y) * rd),
+                           (e0[it].z * sc) * (fmaf(ka, kb[it].z, s.z) * rd), (e0[it].w * sc) * (fmaf(ka, kb[it].w, s.w) * rd)};
+            }
+            // nothing outside the M x N corner is ever non-zero (the padding is a reduction operand of the next GEMM)
+            const bool rv = grow < p.M;
+            o.x = (rv && gcol < p.N) ? o.x : 0.f;
+            o.y = (rv && gcol + 1 < p.N) ? o.y : 0.f;
+            o.z = (rv && gcol + 2 < p.N) ? o.z : 0.f;
+            o.w = (rv && gcol + 3 < p.N) ? o.w : 0.f;
+            if (EPI != DEPI_DIVT && rv && gcol < p.N) *(df32x4*)(p.C + fC + (long)grow * p.ldc + gcol) = o;
+            if (TRANSPOSED) {
+                s_t[(4 * cq + 0) * PT + row] = o.x;
+                s_t[(4 * cq + 1) * PT + row] = o.y;
+                s_t[(4 * cq + 2) * PT + row] = o.z;
+                s_t[(4 * cq + 3) * PT + row] = o.w;
+            }
+        }
+    }
+    if (TRANSPOSED) {
+        __syncthreads();
+        constexpr int R4 = TR / 4;
+        float* Ct = p.Ct + file * p.sCt;
+        for (int id = tid; id < TC * R4; id += NT) {
+            const int ncol = id / R4, rq = id - ncol * R4;
+            const int gn = n0 + ncol, gm = m0 + 4 * rq;
+            if (gn < p.N && gm < p.M) {
+                const float* src = s_t + ncol * PT + 4 * rq;
+                *(df32x4*)(Ct + (long)gn * p.ldct + gm) = df32x4{src[0], src[1], src[2], src[3]};
+            }
+        }
+    }
+    if (side && tid < TC) {
+        const int col = n0 + tid;
+        float t = s_side[tid], r = s_side[NW * TC + tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            t += s_side[w * TC + tid];
+            r += s_side[(NW + w) * TC + tid];
+        }
+        if (col < p.N) {
+            if (p.tailA) {
+                float o = t;
+                if (EPI == DEPI_DIV || EPI == DEPI_DIVT) o = p.E0[file * p.sE0 + (long)p.tail_row * p.lde0 + col] / t;
+                p.C[fC + (long)p.tail_row * p.ldc + col] = o;
+                if (EPI == DEPI_DIVT) p.Ct[file * p.sCt + (long)col * p.ldct + p.tail_row] = o;
+            }
+            if (p.rowsumB) p.rowsumB[file * p.s_rowsumB + col] = r;
+        }
+    }
+}
+
+// ---- launch --------------------------------------------------------------------------------------------------------------
+struct DirectTile { int mb, nb; };
+static const DirectTile direct_tiles[] = {{1, 1}, {1, 2}, {1, 5}, {2, 2}, {2, 4}, {2, 5}, {4, 4}, {4, 5}};
+static const int direct_ntiles = sizeof(direct_tiles) / sizeof(direct_tiles[0]);
+
+static size_t direct_lds_bytes(int mb, int nb, int nw) {
+    const int TR = 16 * mb, TC = 16 * nb;
+    const size_t need = sizeof(float) * ((size_t)nw * TR * (TC + 4) + (size_t)TC * (TR + 1) + 2 * (size_t)nw * TC);
+    // at least 84 KB: never two of these workgroups on one CU (a launch is one round of one workgroup per CU, by construction)
+    return need > 84 * 1024 ? need : 84 * 1024;
+}
+
+template <int MB, int NB, int EPI>
+static int direct_launch_t(const DirectArgs& a, hipStream_t stream) {
+    constexpr int NW = 4;
+    static std::atomic<int> configured[DIRECT_MAX_DEVICES];
+    const size_t lds = direct_lds_bytes(MB, NB, NW);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    if (dev < 0 || dev >= DIRECT_MAX_DEVICES || !configured[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute((const void*)gccnmf_direct_kernel<MB, NB, EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GCCNMF_ERR_LAUNCH;
+        if (dev >= 0 && dev < DIRECT_MAX_DEVICES) configured[dev].store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((gccnmf_direct_kernel<MB, NB, EPI, NW>), dim3(a.batch * 8 * a.sm * a.sn), dim3(64 * NW), lds, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+template <int EPI>
+static int direct_launch_e(const DirectArgs& a, int tile, hipStream_t s) {
+    switch (tile) {
+        case 0: return direct_launch_t<1, 1, EPI>(a, s);
+        case 1: return direct_launch_t<1, 2, EPI>(a, s);
+        case 2: return direct_launch_t<1, 5, EPI>(a, s);
+        case 3: return direct_launch_t<2, 2, EPI>(a, s);
+        case 4: return direct_launch_t<2, 4, EPI>(a, s);
+        case 5: return direct_launch_t<2, 5, EPI>(a, s);
+        case 6: return direct_launch_t<4, 4, EPI>(a, s);
+        case 7: return direct_launch_t<4, 5, EPI>(a, s);
+        default: return GCCNMF_ERR_ARG;
+    }
+}
+
+// Tile choice: the launch should be whole rounds of one workgroup per CU (256), each as short as possible.  Cost of a candidate in
+// matrix-pipe cycles of one wave: rounds x (chunks per wave x max(MFMA time of a chunk, time to fetch it) + a fixed prologue / epilogue).
+static int direct_pick_tile(const DirectArgs& a) {
+    const int nchunks = gccnmf_ceil_div(a.Kd, 16), per_wave = gccnmf_ceil_div(nchunks, 4);
+    int best = -1;
+    double best_cost = 0;
+    for (int t = 0; t < direct_ntiles; ++t) {
+        const int mb = direct_tiles[t].mb, nb = direct_tiles[t].nb;
+        const long wgs = (long)a.batch * gccnmf_ceil_div(a.M, 16 * mb) * gccnmf_ceil_div(a.N, 16 * nb);
+        const long rounds = (wgs + 255) / 256;
+        const double mfma = 4.0 * mb * nb * (mb * nb == 1 ? 40 : 32);
+        const double fetch = 4.0 * (16 * mb + 16 * nb) * 64.0 / 40.0;          // four waves' chunk bytes at ~40 B/clk/CU
+        const double cost = rounds * (per_wave * (mfma > fetch ? mfma : fetch) + 4000.0);
+        if (best < 0 || cost < best_cost * 0.999) {
+            best = t;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream) {
+    if (!a.A || !a.B || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1 || (a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
+    if (epi != DEPI_DIVT && (!a.C || (a.ldc & 3))) return GCCNMF_ERR_ARG;
+    if ((epi == DEPI_DIVT || epi == DEPI_UPDH) && (!a.Ct || (a.ldct & 3))) return GCCNMF_ERR_ARG;
+    if ((epi == DEPI_DIV || epi == DEPI_DIVT) && (!a.E0 || (a.lde0 & 3))) return GCCNMF_ERR_ARG;
+    if (epi == DEPI_UPDH && !a.E2) return GCCNMF_ERR_ARG;
+    if (a.tailA && !a.C) return GCCNMF_ERR_ARG;
+    const int t = tile > 0 ? tile - 1 : direct_pick_tile(a);
+    if (t < 0 || t >= direct_ntiles) return GCCNMF_ERR_ARG;
+    const int TR = 16 * direct_tiles[t].mb, TC = 16 * direct_tiles[t].nb;
+    a.tiles_m = gccnmf_ceil_div(a.M, TR);
+    a.tiles_n = gccnmf_ceil_div(a.N, TC);
+    // XCD grid (8 / xc) x xc: as little of A and B per XCD as possible, sub-grids that cover the tile grid with the fewest idle blocks
+    long best_waste = -1, best_bytes = 0;
+    for (int xc = 1; xc <= 8; xc *= 2) {
+        const int xr = 8 / xc, sm = gccnmf_ceil_div(a.tiles_m, xr), sn = gccnmf_ceil_div(a.tiles_n, xc);
+        const long waste = 8L * sm * sn - (long)a.tiles_m * a.tiles_n, bytes = (long)sm * TR + (long)sn * TC;
+        if (best_waste < 0 || waste < best_waste || (waste == best_waste && bytes < best_bytes)) {
+            best_waste = waste; best_bytes = bytes;
+            a.xc = xc; a.sm = sm; a.sn = sn;
+        }
+    }
+    switch (epi) {
+        case DEPI_STORE: return direct_launch_e<DEPI_STORE>(a, t, stream);
+        case DEPI_DIV: return direct_launch_e<DEPI_DIV>(a, t, stream);
+        case DEPI_DIVT: return direct_launch_e<DEPI_DIVT>(a, t, stream);
+        case DEPI_UPDH: return direct_launch_e<DEPI_UPDH>(a, t, stream);
+        default: return GCCNMF_ERR_ARG;
+    }
+}
+
+extern "C" int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream) {
+    if (!desc || tile < 0) return GCCNMF_ERR_ARG;
+    return gccnmf_direct_launch(*desc, epilogue, tile, (hipStream_t)stream);
+}
+
+// ---- transposed copies ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gccnmf_transpose_kernel(const float* __restrict__ in, long s_in, int ld_in, float* __restrict__ out,
+                                                               long s_out, int ld_out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + b * s_in;
+    float* dst = out + b * s_out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(long)c * ld_out + r] = t[tx][ty + 8 * i];
+    }
+}
+
+int gccnmf_transpose_launch(const float* in, long s_in, int ld_in, float* out, long s_out, int ld_out, int rows, int cols, int batch,
+                            hipStream_t stream) {
+    if (!in || !out || rows < 1 || cols < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    hipLaunchKernelGGL(gccnmf_transpose_kernel, dim3(gccnmf_ceil_div(cols, 32), gccnmf_ceil_div(rows, 32), batch), dim3(256), 0, stream, in, s_in,
+                       ld_in, out, s_out, ld_out, rows, cols);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}

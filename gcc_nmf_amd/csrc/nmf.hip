@@ -12,10 +12,12 @@
 // gccnmf_klnmf materialises it once after the last iteration.
 #include <mutex>
 #include "gemm_ring.h"
+#include "direct.h"
 #include "../../include/gccnmf_hip.h"
 
 int gccnmf_tune_ablate = 0;
 #define GCCNMF_SHARED_STREAMS 4
+#define GCCNMF_DIRECT_MAX_BATCH 16   // workspaces of at most this many files carry the transposed copies of the direct path
 int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
 int gccnmf_tune_tail_split = 1;       // key 9: the files of a launch's partial last round run as half-height tiles (gemm_dma.h)
 int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
@@ -24,6 +26,9 @@ int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 al
 int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
 int gccnmf_tune_wh_splits = 3;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
 int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
+int gccnmf_tune_direct = 1;        // key 10: 1 (default) = launches that cannot fill the chip take the direct-to-register kernels (direct.hip)
+int gccnmf_tune_direct_tile = 0;   // key 11: 0 = tile by the cost model, 1..8 = that tile for every direct launch (experiments)
+int gccnmf_tune_direct_batch = 1;  // key 12: largest batch that takes the direct path
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
@@ -57,6 +62,18 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 7 && (value == 0 || value == 1)) {
         gccnmf_tune_exact_div = value;
+        return GCCNMF_OK;
+    }
+    if (key == 10 && (value == 0 || value == 1)) {
+        gccnmf_tune_direct = value;
+        return GCCNMF_OK;
+    }
+    if (key == 11 && value >= 0 && value <= 8) {
+        gccnmf_tune_direct_tile = value;
+        return GCCNMF_OK;
+    }
+    if (key == 12 && value >= 1 && value <= GCCNMF_DIRECT_MAX_BATCH) {
+        gccnmf_tune_direct_batch = value;
         return GCCNMF_OK;
     }
     if ((key == 5 || key == 6) && value >= 1 && value <= 4) {
@@ -206,7 +223,8 @@ template <int AT, int NSPLIT>
 __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __restrict__ W, const float* __restrict__ U,
                                                                    const float* __restrict__ rowsumH, float* __restrict__ colsumW,
                                                                    float* __restrict__ hscale, int F, int K, int Kp, long sW, long sU,
-                                                                   long sVec, long sRowsum, long sSplitU, long sSplitR) {
+                                                                   long sVec, long sRowsum, long sSplitU, long sSplitR, float* __restrict__ Wt,
+                                                                   long sWt, int ldwt) {
     constexpr int nsplit = NSPLIT;
     constexpr int L4 = AT / 4;                 // float4 lanes per row segment
     constexpr int PH = 256 / L4;               // row phases per workgroup (PH / 4 per wave)
@@ -282,6 +300,10 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
             const float4 wn = make_float4(v0 ? wt[r].x / nm.x : 0.f, v1 ? wt[r].y / nm.y : 0.f, v2 ? wt[r].z / nm.z : 0.f,
                                           v3 ? wt[r].w / nm.w : 0.f);
             *(float4*)(Wb + (long)f * Kp + k0) = wn;
+            if (Wt) {            // the reduction-major copy the direct path's W.H reads (padded atoms: zero rows)
+                float* t = Wt + b * sWt + (long)k0 * ldwt + f;
+                t[0] = wn.x; t[ldwt] = wn.y; t[2 * (long)ldwt] = wn.z; t[3 * (long)ldwt] = wn.w;
+            }
             cs.x += wn.x; cs.y += wn.y; cs.z += wn.z; cs.w += wn.w;
         }
     }
@@ -298,12 +320,12 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
 
 static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,
                            int Kp, long sW, long sU, long sVec, long sRowsum, int batch, hipStream_t s, int nsplit = 1,
-                           long sSplitU = 0, long sSplitR = 0) {
+                           long sSplitU = 0, long sSplitR = 0, float* Wt = nullptr, long sWt = 0, int ldwt = 0) {
     if ((long)batch * (Kp / 64) < 256 && gccnmf_tune_ring && F <= 64 * 9 && (nsplit == 1 || nsplit == 2 || nsplit == 4)) {
         // 16 atoms per workgroup (64-byte row segments); 8 (twice the workgroups, 32-byte segments) measured slower: 13.0 vs 11.4 us for one
         // file at K = 1024 -- kept selectable for experiments (tuning key 1 = 64)
 #define GCCNMF_ONEPASS(AT_, NS_) hipLaunchKernelGGL((nmf_update_w_onepass_kernel<AT_, NS_>), dim3(batch * (Kp / AT_)), dim3(256), 0, s, W, U, rowsumH, \
-                                                    colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR)
+                                                    colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR, Wt, sWt, ldwt)
         const bool narrow = gccnmf_tune_ablate == 64;
         if (narrow) {
             if (nsplit == 1) GCCNMF_ONEPASS(8, 1);
@@ -326,6 +348,7 @@ static int launch_update_w(float* W, const float* U, const float* rowsumH, float
                            Kp, sW, sU, sVec, sRowsum, nsplit, sSplitU, sSplitR);
     }
     GCCNMF_CHECK_LAUNCH();
+    if (Wt) return gccnmf_transpose_launch(W, sW, Kp, Wt, sWt, ldwt, F, Kp, batch, s);      // (the one-pass kernel writes it itself)
     return GCCNMF_OK;
 }
 
@@ -587,16 +610,101 @@ static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, fl
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------
+// The direct path (csrc/direct.hip): launches that cannot fill the chip -- one mixture alone, the shape behind the reference's
+// own function names (runGCCNMF.py:41 -> performKLNMF(V, dictionarySize, 100, 0))
+// ------------------------------------------------------------------------------------------
+// All four GEMMs of an iteration as "both operands reduction-major" products, one round of one workgroup per CU each, the
+// reduction split inside the workgroup (no partial products through HBM, no combine launches):
+//   K1  R  = V / (Wt^T . (s*H))           A = Wt [k][f]   B = H  [k][n]      -> R [f][n]
+//   K2  H  = (s*H) * (W^T . R) / (...)    A = W  [f][k]   B = R  [f][n]      -> H [k][n] and Ht [n][k]
+//   K3  Rt = (V / (Wt^T . H))^T           A = Wt [k][f]   B = H  [k][n]      -> Rt [n][f] (+ the Nyquist row into R)
+//   K4  U  = Rt^T . Ht, rowsumH           A = Rt [n][f]   B = Ht [n][k]      -> U [f][k]
+//   K4b W update (one pass)                                                   -> W [f][k] and Wt [k][f]
+// The transposed copies (Wt, Ht, Rt) live behind the other scratch in the workspace.  F = 16 n + 1 (513): bin F-1 is the VALU tail
+// row of K1 / K3 / K4 and the rank-1 epilogue term of K2.
+struct DirectBufs {
+    float *Wt, *Ht, *Rt;
+    long sWt, sHt, sRt;
+    int ldwt, ldht, ldrt;
+};
+static long direct_floats(const NmfGeom& g, int batch) { return batch <= GCCNMF_DIRECT_MAX_BATCH ? (long)batch * (g.sU + g.sH + g.sV) : 0; }
+static bool direct_path(const NmfGeom& g, int batch) {
+    return gccnmf_tune_direct && gccnmf_tune_tile_policy == 0 && batch <= gccnmf_tune_direct_batch && batch <= GCCNMF_DIRECT_MAX_BATCH;
+}
+static DirectBufs direct_bufs(const NmfGeom& g, float* base, int batch) {
+    DirectBufs d;
+    d.sWt = (long)g.Kp * g.Fp; d.sHt = (long)g.Np * g.Kp; d.sRt = (long)g.Np * g.Fp;
+    d.ldwt = g.Fp; d.ldht = g.Kp; d.ldrt = g.Fp;
+    d.Wt = base;
+    d.Ht = d.Wt + batch * d.sWt;
+    d.Rt = d.Ht + batch * d.sHt;
+    return d;
+}
+static bool direct_tail(const NmfGeom& g) { return g.F > 16 && (g.F % 16) == 1; }
+
+// K1 (hscale != nullptr) and K3 (transposed output)
+static int direct_wh_div(const NmfGeom& g, const DirectBufs& d, const float* V, const float* W, const float* H, const float* hscale, float* R,
+                         bool transposed, int batch, hipStream_t s) {
+    DirectArgs a = {};
+    a.A = d.Wt; a.sA = d.sWt; a.lda = d.ldwt;
+    a.B = H; a.sB = g.sH; a.ldb = g.ld;
+    a.M = direct_tail(g) ? g.F - 1 : g.F; a.N = g.N; a.Kd = g.K; a.batch = batch;
+    a.bscale = hscale; a.s_bscale = g.Kp;
+    if (direct_tail(g)) {
+        a.tailA = W + (long)(g.F - 1) * g.Kp; a.s_tailA = g.sW; a.tail_row = g.F - 1;
+    }
+    a.C = R; a.sC = g.sV; a.ldc = g.ld;
+    a.E0 = V; a.sE0 = g.sV; a.lde0 = g.ld;
+    if (transposed) {
+        a.Ct = d.Rt; a.sCt = d.sRt; a.ldct = d.ldrt;
+    }
+    return gccnmf_direct_launch(a, transposed ? DEPI_DIVT : DEPI_DIV, gccnmf_tune_direct_tile, s);
+}
+
+static int direct_update_h(const NmfGeom& g, const DirectBufs& d, const float* W, const float* R, float* H, const float* hscale,
+                           const float* colsumW, float alpha, float eps, int batch, hipStream_t s) {
+    DirectArgs a = {};
+    a.A = W; a.sA = g.sW; a.lda = g.Kp;
+    a.B = R; a.sB = g.sV; a.ldb = g.ld;
+    a.M = g.K; a.N = g.N; a.Kd = g.F; a.batch = batch;
+    if (direct_tail(g)) {
+        a.Kd = g.F - 1;
+        a.ktailA = W + (long)(g.F - 1) * g.Kp; a.s_ktailA = g.sW;
+        a.ktailB = R + (long)(g.F - 1) * g.ld; a.s_ktailB = g.sV;
+    }
+    a.C = H; a.sC = g.sH; a.ldc = g.ld;
+    a.Ct = d.Ht; a.sCt = d.sHt; a.ldct = d.ldht;
+    a.E1 = hscale; a.sE1 = g.Kp;
+    a.E2 = colsumW; a.sE2 = g.Kp;
+    a.alpha = alpha; a.eps = eps;
+    return gccnmf_direct_launch(a, DEPI_UPDH, gccnmf_tune_direct_tile, s);
+}
+
+static int direct_rht(const NmfGeom& g, const DirectBufs& d, const float* R, float* U, float* rowsumH, int batch, hipStream_t s) {
+    DirectArgs a = {};
+    a.A = d.Rt; a.sA = d.sRt; a.lda = d.ldrt;
+    a.B = d.Ht; a.sB = d.sHt; a.ldb = d.ldht;
+    a.M = direct_tail(g) ? g.F - 1 : g.F; a.N = g.K; a.Kd = g.N; a.batch = batch;
+    if (direct_tail(g)) {
+        a.tailA = R + (long)(g.F - 1) * g.ld; a.s_tailA = g.sV; a.tail_row = g.F - 1;
+    }
+    a.rowsumB = rowsumH; a.s_rowsumB = g.Kp;
+    a.C = U; a.sC = g.sU; a.ldc = g.Kp;
+    return gccnmf_direct_launch(a, DEPI_STORE, gccnmf_tune_direct_tile, s);
+}
+
 extern "C" {
 
 // R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
 // GCCNMF_SPLITS x max(Fp*Np, Fp*Kp) (W.H parts and R.H^T parts use the same memory at different stages) + GCCNMF_SPLITS x Kp
+// | (batch <= GCCNMF_DIRECT_MAX_BATCH) the transposed copies of the direct path: Wt [batch][Kp][Fp], Ht [batch][Np][Kp], Rt [batch][Np][Fp]
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
     long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
     if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
-    return n;
+    return n + direct_floats(g, batch);                       // Wt | Ht | Rt of the direct path (a handful of files at most)
 }
 
 // One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
@@ -610,6 +718,31 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* hscale = rowsumH + (long)batch * g.Kp;
     float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
+    if (direct_path(g, batch)) {
+        const DirectBufs d = direct_bufs(g, batch == 1 ? rowsum_parts + GCCNMF_SPLITS * (long)g.Kp : parts, batch);
+        switch (stage) {
+            case 0: {
+                // zero: R's padding (reduction operand of K2), Rt / Ht rows n >= N (reduction operands of K4), Wt columns f >= F
+                if (hipMemsetAsync(R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+                if (hipMemsetAsync(d.Wt, 0, sizeof(float) * direct_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+                hipLaunchKernelGGL(nmf_prepare_kernel, dim3(batch * (g.Kp / 16)), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
+                GCCNMF_CHECK_LAUNCH();
+                return gccnmf_transpose_launch(W, g.sW, g.Kp, d.Wt, d.sWt, d.ldwt, g.F, g.Kp, batch, s);
+            }
+            case 1: return direct_wh_div(g, d, V, W, H, hscale, R, false, batch, s);
+            case 2: return direct_update_h(g, d, W, R, H, hscale, colsumW, alpha, eps, batch, s);
+            case 3: return direct_wh_div(g, d, V, W, H, nullptr, R, true, batch, s);
+            case 4: return direct_rht(g, d, R, U, rowsumH, batch, s);
+            case 5:
+                return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s, 1, 0, 0,
+                                       d.Wt, d.sWt, d.ldwt);
+            case 6:
+                hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.sH, g.ld, g.Np);
+                GCCNMF_CHECK_LAUNCH();
+                return GCCNMF_OK;
+            default: return GCCNMF_ERR_ARG;
+        }
+    }
     const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
     const int xcd = ((flags & 1) ? 0 : 1) | ((flags & 4) ? 2 : 0);      // bit 1: another file group's launches run beside these

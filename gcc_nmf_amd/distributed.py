@@ -140,12 +140,14 @@ class _SharedRun(object):
     device, F, K, alpha, eps, Wd, partial, vec and _shards() -> [(V, H, workspace, N, batch, ld)] (device tensors)."""
 
     @_on_device
-    def run(self, numIterations, group=None):
+    def run(self, numIterations, group=None, collective=True):
+        """collective=False: this object's columns alone, no all-reduce even inside an initialised process group (performKLNMF on one
+        big matrix)."""
         descs = self._shards()
         arr = (_hip.SharedShard * max(len(descs), 1))()
         for d, (V, H, ws, N, batch, ld) in zip(arr, descs):
             d.V, d.H, d.workspace, d.N, d.batch, d.ld = _ptr(V), _ptr(H), _ptr(ws), N, batch, ld
-        fn, ctx, keep, self.collective = collective_hook(self.partial, group)
+        fn, ctx, keep, self.collective = collective_hook(self.partial, group) if collective else (None, None, None, 'none (local columns only)')
         if fn is not None:
             torch.cuda.current_stream(self.device).synchronize()      # nothing of torch's own collectives is still in flight on the devices
         rc = self.lib.gccnmf_klnmf_shared_run(arr, len(descs), _ptr(self.Wd), _ptr(self.partial), _ptr(self.vec), self.F, self.K,

@@ -85,6 +85,8 @@ def performKLNMF(V, dictionarySize, numIterations, sparsityAlpha, epsilon=1e-16,
     F, N = V.shape
     K = int(dictionarySize)
     lib, dev = _hip.lib(), _device()
+    if N > LARGE_N_COLUMNS:
+        return _performKLNMF_column_blocks(V, K, int(numIterations), float(sparsityAlpha), float(epsilon), seedValue, dev)
     b = _klnmf_buffers(F, N, K, dev)
     g = b['g']
     # The initial factors depend on (seedValue, F, K, N, epsilon) only, and so does the state the reference leaves the GLOBAL generator
@@ -110,6 +112,30 @@ def performKLNMF(V, dictionarySize, numIterations, sparsityAlpha, epsilon=1e-16,
     _hip.check(lib.gccnmf_klnmf(_ptr(b['V']), _ptr(b['W']), _ptr(b['H']), _ptr(b['ws']), F, N, K, 1, int(numIterations),
                                 float(sparsityAlpha), float(epsilon), 0, _stream()), 'gccnmf_klnmf')
     return b['W'][:F, :K].cpu().numpy(), b['H'][:K, :N].cpu().numpy()
+
+
+# One BIG matrix (the dictionary pre-training set, gccNMF/realtime/gccNMFPretraining.py:79-80: performKLNMF on thousands of frames):
+# beyond this many columns the launch fills the chip by itself, and the columns are handed to the batched throughput kernels IN PLACE
+# as column blocks of one matrix (gccnmf_klnmf_shared_run with ld > 0 -- the machinery of the time-sharded mode, one rank, no
+# collective) instead of the one-mixture latency path.  Same update (gccNMFFunctions.py:75-81): W's numerator sums over all blocks.
+LARGE_N_COLUMNS = 4096
+
+
+def _performKLNMF_column_blocks(V, K, numIterations, sparsityAlpha, epsilon, seedValue, dev):
+    from .distributed import HipSharedColumns
+    F, N = V.shape
+    g = Geometry(F, 1, K)
+    ld = -(-N // 64) * 64
+    seed(seedValue)                                     # the reference's draws, W before H, and its side effect on the global generator
+    W0 = random((F, K)).astype(float32) + epsilon
+    H0 = random((K, N)).astype(float32) + epsilon
+    with torch.cuda.device(dev):
+        Vd = padded(np.ascontiguousarray(V, dtype=float32), (g.Fp, ld), dev)
+        Wd = padded(W0.astype(float32), (g.Fp, g.Kp), dev)
+        Hd = padded(H0.astype(float32), (g.Kp, ld), dev)
+        run = HipSharedColumns(Vd, Hd, Wd, F, N, K, sparsityAlpha, epsilon)
+        run.run(numIterations, collective=False)        # this call's columns only, whatever process group the caller may have set up
+        return Wd[:F, :K].cpu().numpy(), Hd[:K, :N].cpu().numpy()
 
 
 _KLNMF_BUFFERS = {}          # (F, N, K, device) -> padded device buffers + workspace, a few most recent shapes

@@ -304,6 +304,55 @@ int gccnmf_debug_set_trace(long long* buf, int blocks);
  * the matrix-pipe rate this box sustains, quoted next to the roofline fractions. */
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);
 
+/* Latency-path GEMM with the KL-NMF element-wise work fused (csrc/direct.hip): what gccnmf_klnmf runs for ONE mixture alone
+ * (performKLNMF(V (513, 1244), 1024, 100, 0) is four of these + the W update per iteration), exported so that it can be tested
+ * and timed in isolation.
+ *     C[m][n] = sum_r A[r][m] * (bscale[r] *) B[r][n]        r < Kd, m < M, n < N
+ * BOTH operands are reduction-major: one reduction index per row (pitches lda / ldb, multiples of 4), the output index contiguous
+ * -- rows r < round_up(Kd, 16) must be addressable, and zero beyond Kd in at least one operand.  Every pointer is device memory;
+ * per-file strides (s*) are in floats.  epilogue (numpy.dot / element-wise lines of gccNMFFunctions.py:76-77):
+ *   0 STORE  C = acc;  optional rowsumB[n] = sum_r B[r][n];
+ *   1 DIV    C = E0 / acc                                   (E0 has pitch lde0)
+ *   2 DIVT   Ct[n][m] = E0[m][n] / acc                      (transposed output only)
+ *   3 UPDH   C = (C * E1[m]) * ((acc + ktailA[m] * ktailB[n]) / (E2[m] + alpha + eps)), also stored transposed into Ct
+ * tailA != NULL adds output row `tail_row` = sum_r tailA[r] * B[r][n], computed on the VALU (F = 513 = 16 * 32 + 1), with the
+ * epilogue applied (it goes to C, and to Ct as well for DIVT).  Nothing outside the M x N corner (plus the tail row) is written,
+ * except zeros inside a 4-float group that straddles it.  tile: 0 = chosen by the library, 1..8 = a fixed tile (experiments).
+ * The trailing five fields are filled in by the library. */
+typedef struct gccnmf_direct_gemm {
+    const float* A;
+    const float* B;
+    long sA, sB;
+    int lda, ldb;
+    int M, N, Kd, batch;
+    const float* bscale;
+    long s_bscale;
+    const float* tailA;
+    long s_tailA;
+    int tail_row;
+    float* rowsumB;
+    long s_rowsumB;
+    float* C;
+    long sC;
+    int ldc;
+    float* Ct;
+    long sCt;
+    int ldct;
+    const float* E0;
+    long sE0;
+    int lde0;
+    const float* E1;
+    long sE1;
+    const float* E2;
+    long sE2;
+    const float* ktailA;
+    const float* ktailB;
+    long s_ktailA, s_ktailB;
+    float alpha, eps;
+    int tiles_m, tiles_n, xc, sm, sn;
+} gccnmf_direct_gemm;
+int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream);
+
 /* Diagnostics (tests only): run one MFMA GEMM configuration in isolation.
  * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid,
  * 16 = last reduction index as a rank-1 epilogue term (non-KC operands). */

@@ -113,6 +113,108 @@ def test_debug_gemm(hip, layout, M, N, Kd, batch):
 
 
 # ------------------------------------------------------------------------------------------------
+# the latency-path GEMM (csrc/direct.hip): every epilogue x every tile, ragged shapes, batches, tail row, lazy scale
+# ------------------------------------------------------------------------------------------------
+DIRECT_CASES = [
+    # (epilogue, tile, M, N, Kd, batch, tail, scale)      tile 0 = the library's choice, 1..8 = fixed
+    (0, 0, 100, 70, 50, 1, False, False), (0, 5, 513, 1024, 1244, 1, True, False), (0, 1, 33, 20, 200, 2, True, False),
+    (0, 2, 48, 40, 37, 3, False, False), (0, 4, 70, 33, 64, 1, True, False), (0, 7, 130, 100, 96, 2, False, False),
+    (1, 0, 513, 1244, 128, 1, True, True), (1, 6, 513, 300, 1024, 1, True, True), (1, 3, 40, 90, 33, 2, False, True),
+    (1, 8, 200, 170, 80, 1, False, False), (1, 6, 65, 81, 16, 3, True, False),
+    (2, 0, 513, 1244, 64, 1, True, False), (2, 6, 513, 200, 100, 2, True, False), (2, 8, 100, 163, 48, 1, False, False),
+    (2, 3, 30, 50, 20, 1, False, False),
+    (3, 0, 1024, 1244, 513, 1, True, False), (3, 8, 128, 300, 513, 2, True, False), (3, 3, 64, 100, 40, 1, False, False),
+    (3, 6, 100, 77, 129, 2, True, False), (3, 7, 70, 64, 32, 1, False, False),
+]
+
+
+@pytest.mark.parametrize('epi,tile,M,N,Kd,batch,tail,scale', DIRECT_CASES)
+def test_gemm_direct(hip, epi, tile, M, N, Kd, batch, tail, scale):
+    """C = A^T . B with both operands reduction-major, against float64; for UPDH `tail` = the rank-1 epilogue term."""
+    lib = hip.lib()
+    rng = np.random.RandomState(epi * 7919 + tile * 131 + M + N + Kd)
+    Kd16 = -(-Kd // 16) * 16
+    Mm = M - 1 if (tail and epi != 3) else M                  # rows on the matrix cores; row M-1 is the VALU tail row
+    Kdm = Kd - 1 if (tail and epi == 3) else Kd               # UPDH: the last reduction index is the rank-1 term
+    Kd16 = -(-Kdm // 16) * 16
+    lda, ldb = -(-M // 4) * 4 + 4, -(-N // 4) * 4 + 8
+    A = (rng.rand(batch, Kd, M) + 0.25).astype(np.float32)
+    B = (rng.rand(batch, Kd, N) + 0.25).astype(np.float32)
+    Ad = np.zeros((batch, Kd16 + 16, lda), np.float32)
+    Bd = np.zeros((batch, Kd16 + 16, ldb), np.float32)
+    Ad[:, :Kdm, :Mm] = A[:, :Kdm, :Mm]
+    Bd[:, :Kdm, :N] = B[:, :Kdm]
+    dA, dB = dev(Ad), dev(Bd)
+    ldc, ldct = ldb, lda
+    C0 = (rng.rand(batch, M, N) + 0.5).astype(np.float32)          # UPDH: the old H
+    Cd = np.full((batch, M, ldc), -7.0, np.float32)
+    if epi == 3:
+        Cd[:, :, :N] = C0
+    dC = dev(Cd)
+    dCt = torch.full((batch, N, ldct), -7.0, dtype=torch.float32, device='cuda')
+    E0 = (rng.rand(batch, M, N) + 0.5).astype(np.float32)
+    E0d = np.zeros((batch, M, ldc), np.float32)
+    E0d[:, :, :N] = E0
+    dE0 = dev(E0d)
+    bs = (rng.rand(batch, Kd16) + 0.5).astype(np.float32)
+    dbs = dev(bs)
+    tailA = np.zeros((batch, Kd16), np.float32)
+    tailA[:, :Kd] = A[:, :, M - 1]
+    dtail = dev(tailA)
+    drow = torch.full((batch, N), -7.0, dtype=torch.float32, device='cuda')
+    E1 = (rng.rand(batch, M) + 0.5).astype(np.float32)
+    E2 = (rng.rand(batch, M) + 0.5).astype(np.float32)
+    dE1, dE2 = dev(E1), dev(E2)
+    kA = np.ascontiguousarray(A[:, Kd - 1, :])                      # [batch][M]
+    kB = np.zeros((batch, ldb), np.float32)
+    kB[:, :N] = B[:, Kd - 1, :]
+    dkA, dkB = dev(kA), dev(kB)
+    d = hip.DirectGemm()
+    d.A, d.B, d.sA, d.sB, d.lda, d.ldb = dA.data_ptr(), dB.data_ptr(), Ad[0].size, Bd[0].size, lda, ldb
+    d.M, d.N, d.Kd, d.batch = Mm, N, Kdm, batch
+    if scale:
+        d.bscale, d.s_bscale = dbs.data_ptr(), Kd16
+    if tail and epi != 3:
+        d.tailA, d.s_tailA, d.tail_row = dtail.data_ptr(), Kd16, M - 1
+    if epi == 0:
+        d.rowsumB, d.s_rowsumB = drow.data_ptr(), N
+    d.C, d.sC, d.ldc = dC.data_ptr(), M * ldc, ldc
+    d.Ct, d.sCt, d.ldct = dCt.data_ptr(), N * ldct, ldct
+    d.E0, d.sE0, d.lde0 = dE0.data_ptr(), M * ldc, ldc
+    d.E1, d.sE1, d.E2, d.sE2 = dE1.data_ptr(), M, dE2.data_ptr(), M
+    if tail and epi == 3:
+        d.ktailA, d.ktailB, d.s_ktailA, d.s_ktailB = dkA.data_ptr(), dkB.data_ptr(), M, ldb
+    d.alpha, d.eps = 0.25, 1e-16
+    assert lib.gccnmf_gemm_direct(ctypes.byref(d), epi, tile, stream()) == 0
+    torch.cuda.synchronize()
+    C, Ct = dC.cpu().numpy(), dCt.cpu().numpy()
+    Bs = B.astype(np.float64) * (bs[:, :Kd, None] if scale else 1.0)
+    acc = np.einsum('bkm,bkn->bmn', A.astype(np.float64), Bs)              # all M rows, all Kd reduction indexes
+    if epi == 0:
+        ref = acc
+    elif epi in (1, 2):
+        ref = E0 / acc
+    else:
+        ref = (C0.astype(np.float64) * E1[:, :, None]) * (acc / (E2[:, :, None].astype(np.float64) + 0.25 + 1e-16))
+    rows = M if (tail or epi == 3) else Mm
+    tol = 3e-6 * np.abs(ref).max() * max(1.0, np.sqrt(Kd / 64.0))
+    if epi != 2:
+        assert np.abs(C[:, :rows, :N] - ref[:, :rows]).max() < tol
+        assert np.all(C[:, :, N:] == -7.0) or np.all((C[:, :, N:] == -7.0) | (C[:, :, N:] == 0.0)), 'wrote garbage outside the valid columns'
+    if epi == 2:
+        assert np.abs(Ct[:, :, :M].transpose(0, 2, 1)[:, :rows] - ref[:, :rows]).max() < tol
+        if tail:
+            assert np.abs(C[:, M - 1, :N] - ref[:, M - 1]).max() < tol          # the tail row also lands in the row-major buffer
+    if epi == 3:
+        assert np.abs(Ct[:, :, :M].transpose(0, 2, 1) - ref).max() < tol
+    if epi in (2, 3):
+        pad = Ct[:, :, -(-M // 4) * 4:]
+        assert np.all(pad == -7.0), 'transposed store wrote beyond the 4-float group that holds row M-1'
+    if epi == 0:
+        assert np.abs(drow.cpu().numpy() - Bs.sum(axis=1)).max() < 1e-5 * Kd
+
+
+# ------------------------------------------------------------------------------------------------
 # STFT / iSTFT
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('n_fft,hop,n', [(1024, 256, 20000), (1024, 128, 6000), (512, 64, 5000), (256, 100, 3000), (2048, 512, 9000),
@@ -265,6 +367,58 @@ def test_klnmf_vs_oracle(hip, F, N, K, iters, alpha, tile_policy):
     performKLNMF(V, K, 0, 0)
     assert np.random.random() == expected_next
     np.random.set_state(state)
+
+
+@pytest.mark.parametrize('N,K,iters', [(20000, 64, 4), (80000, 48, 3), (4100, 128, 5)])
+def test_klnmf_one_big_matrix_takes_the_column_block_path(hip, N, K, iters):
+    """performKLNMF on ONE big matrix (the dictionary pre-training call, gccNMFPretraining.py:79-80): beyond 4096 columns the
+    reference-named function hands the columns to the batched throughput kernels as in-place column blocks."""
+    from gcc_nmf_amd import gccNMFFunctions as G
+    assert N > G.LARGE_N_COLUMNS
+    rng = np.random.RandomState(N + K)
+    V = (np.abs(rng.standard_normal((513, N))) + 0.01).astype(np.float32)
+    W, H = G.performKLNMF(V, K, iters, 0)
+    Wr, Hr = O.performKLNMF(V, K, iters, 0)
+    assert W.shape == Wr.shape and H.shape == Hr.shape
+    assert rel(W, Wr) < 1e-4 and rel(H, Hr) < 1e-4, (rel(W, Wr), rel(H, Hr))
+    assert np.allclose(np.linalg.norm(W, axis=0), 1.0, atol=1e-5)
+
+
+def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
+    """The direct-to-register latency path (csrc/direct.hip) and the round-3 split-K path compute the same factors (different summation
+    grouping: equal to round-off), alone and for a handful of files (tuning key 12 lets small batches take the direct path)."""
+    lib = hip.lib()
+    F, T, K, B = 513, 311, 256, 3
+    g = hip_geometry(F, T, K)
+    rng = np.random.RandomState(3)
+    V = (np.abs(rng.standard_normal((B, F, 2 * T))) + 0.01).astype(np.float32)
+    from gcc_nmf_amd.engine import klnmf_initial_factors, padded
+    W0, H0 = klnmf_initial_factors(F, 2 * T, K)
+    res = {}
+    for name, direct, maxb, batch in [('split', 0, 1, 1), ('direct', 1, 1, 1), ('direct-batch', 1, 4, B), ('ring-batch', 0, 1, B)]:
+        assert lib.gccnmf_set_tuning(10, direct) == 0 and lib.gccnmf_set_tuning(12, maxb) == 0
+        Vd = padded(V[:batch], (batch, g.Fp, g.Np), 'cuda')
+        Wd = padded(np.repeat(W0[None], batch, 0), (batch, g.Fp, g.Kp), 'cuda')
+        Hd = padded(np.repeat(H0[None], batch, 0), (batch, g.Kp, g.Np), 'cuda')
+        ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, 2 * T, K, batch), dtype=torch.float32, device='cuda')
+        assert lib.gccnmf_klnmf(Vd.data_ptr(), Wd.data_ptr(), Hd.data_ptr(), ws.data_ptr(), F, 2 * T, K, batch, 7, 0.0, 1e-16, 0, stream()) == 0
+        torch.cuda.synchronize()
+        res[name] = (Wd.cpu().numpy(), Hd.cpu().numpy())
+    lib.gccnmf_set_tuning(10, 1)
+    lib.gccnmf_set_tuning(12, 1)
+    for b in range(B):
+        Wr, Hr = O.performKLNMF(V[b], K, 7, 0)
+        for name in ('direct-batch', 'ring-batch') + (('split', 'direct') if b == 0 else ()):
+            W, H = res[name]
+            assert rel(W[b, :F, :K], Wr) < 1e-4 and rel(H[b, :K, :2 * T], Hr) < 1e-4, (name, b)
+            # the padding stays exactly zero (it is a reduction operand)
+            assert not W[b, F:].any() and not W[b, :, K:].any() and not H[b, K:].any() and not H[b, :, 2 * T:].any(), (name, b)
+    assert rel(res['direct'][0], res['split'][0]) < 2e-5
+
+
+def hip_geometry(F, T, K):
+    from gcc_nmf_amd.engine import Geometry
+    return Geometry(F, T, K)
 
 
 def test_klnmf_batch_is_file_independent(hip):

@@ -40,8 +40,10 @@ def test_pitches_and_workspace_sizes():
     assert [x.value for x in v] == [528, 128, 1280, 640]
     assert lib.gccnmf_pitches(1, 622, 128, *[ctypes.byref(x) for x in v]) == 1           # GCCNMF_ERR_ARG
     base = 528 * 1280 + 528 * 1024 + 3 * 1024                      # R, U, three K-vectors per file
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * base
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024)      # + the split-K partials of one file alone
+    direct = 1024 * 528 + 1280 * 1024 + 1280 * 528                 # Wt, Ht, Rt: the transposed copies of the direct path, per file
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * (base + direct)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 64) == 64 * base                           # (a handful of files at most)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + direct      # + the split-K partials of one file alone
     assert lib.gccnmf_klnmf_workspace_floats(513, 0, 1024, 1) == -1
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.gccnmf_klnmf(0, 0, 0, 0, 513, 1244, 1024, 1, 1, 0.0, 1e-16, 0, 0) == 1
@@ -71,6 +73,9 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_run(None, 9, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # > GCCNMF_MAX_SHARDS
     assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
     assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 3) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
+    assert lib.gccnmf_set_tuning(10, 2) == 1 and lib.gccnmf_set_tuning(11, 9) == 1 and lib.gccnmf_set_tuning(12, 17) == 1
+    d = _hip.DirectGemm()
+    assert lib.gccnmf_gemm_direct(None, 0, 0, None) == 1 and lib.gccnmf_gemm_direct(ctypes.byref(d), 0, 0, None) == 1        # null operands
     assert lib.gccnmf_rccl_comm_init(None, 2, 0, None) == 1 and lib.gccnmf_rccl_allreduce(None, None, 4, None) == 1
     assert lib.gccnmf_stft_dft(0, 0, 0, 1000, 250, 1, 1, 0, 0, 0, 0) == 1 and lib.gccnmf_dft_workspace_floats(1000, 0, 2) == -1
 
