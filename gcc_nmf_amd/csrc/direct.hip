@@ -71,8 +71,9 @@ struct DirectFrag {
     df32x4 sc, tl;                                // lazy scale of B / tail-row values of A for reduction indexes 4g .. 4g + 3
 };
 
-template <int MB, int NB, int EPI, int NW>
+template <int MB, int NB, int EPI, int NW, int NBUF>
 __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectArgs p) {
+    static_assert(NBUF >= 2 && NBUF <= 4, "register sets of the operand pipeline (NBUF - 1 chunks in flight)");
     static_assert(MB == 1 || MB == 2 || MB == 4, "rows of a tile: 16, 32 or 64");
     static_assert(NB % 4 != 3, "column groups: float4s plus one float2 or float");
     constexpr int TR = 16 * MB, TC = 16 * NB;
@@ -174,11 +175,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         }
     };
     auto main_loop = [&](auto side_c, auto sc_c) {
-        Frag f0, f1;
-        load(side_c, sc_c, f0, wave);
-        // One scheduling region per chunk: the next chunk's loads dealt out between this chunk's MFMAs (one load per MPL MFMAs), so the
-        // memory pipeline takes them at its own pace while the matrix pipe stays busy.  Left alone, the scheduler sinks every load
-        // to just before its first use to save registers, and the loop waits for a full memory round trip per chunk.
+        // Operand pipeline: NBUF register sets, the loads of chunk i + NBUF - 1 are issued while chunk i is multiplied (what has to be
+        // covered is a first touch of the operands per XCD -- every kernel of the iteration reads what the previous one wrote, so a line
+        // comes from the memory side once per XCD, and the 32 workgroups of an XCD that share it wait for it together).
+        // One scheduling region per chunk: the loads are dealt out between the chunk's MFMAs (one per MPL MFMAs), so the memory
+        // pipeline takes them at its own pace while the matrix pipe stays busy.  Left alone, the scheduler sinks every load to just
+        // before its first use to save registers, and the loop waits for a full memory round trip per chunk.
         constexpr int NLOADS = 4 * (1 + G4 + (REM ? 1 : 0)) + (decltype(side_c)::value ? 1 : 0) + (decltype(sc_c)::value ? 1 : 0);
         constexpr int NMFMA = 16 * MB * NB / 4;
         constexpr int MPL = NMFMA / NLOADS > 0 ? NMFMA / NLOADS : 1;
@@ -189,19 +191,24 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         };
+        Frag f[NBUF];
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j) load(side_c, sc_c, f[j], wave + j * NW);
         int it = 0;
-        for (; it + 1 < niter; it += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            load(side_c, sc_c, f1, wave + (it + 1) * NW);
-            compute(side_c, sc_c, f0);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            load(side_c, sc_c, f0, wave + (it + 2) * NW);
-            compute(side_c, sc_c, f1);
-            interleave();
+        for (; it + NBUF <= niter; it += NBUF) {
+#pragma unroll
+            for (int j = 0; j < NBUF; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(side_c, sc_c, f[(j + NBUF - 1) % NBUF], wave + (it + j + NBUF - 1) * NW);
+                compute(side_c, sc_c, f[j]);
+                interleave();
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (it < niter) compute(side_c, sc_c, f0);        // odd count: the last chunk is already in f0
+        // fewer than NBUF chunks left: they are in flight or landed already (chunk it + j in set j)
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j)
+            if (it + j < niter) compute(side_c, sc_c, f[j]);
     };
     // loop copies, chosen once per workgroup: with / without the side work of the row-0 tiles, with / without the lazy-scale multiplies
     if constexpr (EPI == DEPI_UPDH) {
@@ -353,21 +360,33 @@ static size_t direct_lds_bytes(int mb, int nb, int nw) {
     return need > 84 * 1024 ? need : 84 * 1024;
 }
 
-template <int MB, int NB, int EPI>
-static int direct_launch_t(const DirectArgs& a, hipStream_t stream) {
+extern int gccnmf_tune_direct_depth;
+template <int MB, int NB, int EPI, int NBUF>
+static int direct_launch_n(const DirectArgs& a, hipStream_t stream) {
     constexpr int NW = 4;
     static std::atomic<int> configured[DIRECT_MAX_DEVICES];
     const size_t lds = direct_lds_bytes(MB, NB, NW);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     if (dev < 0 || dev >= DIRECT_MAX_DEVICES || !configured[dev].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute((const void*)gccnmf_direct_kernel<MB, NB, EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)gccnmf_direct_kernel<MB, NB, EPI, NW, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return GCCNMF_ERR_LAUNCH;
         if (dev >= 0 && dev < DIRECT_MAX_DEVICES) configured[dev].store(1, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((gccnmf_direct_kernel<MB, NB, EPI, NW>), dim3(a.batch * 8 * a.sm * a.sn), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL((gccnmf_direct_kernel<MB, NB, EPI, NW, NBUF>), dim3(a.batch * 8 * a.sm * a.sn), dim3(64 * NW), lds, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+// register sets of the operand pipeline: tuning key 13 (0 = by tile: three sets, four for the smallest tiles)
+template <int MB, int NB, int EPI>
+static int direct_launch_t(const DirectArgs& a, hipStream_t stream) {
+    // measured on one mixture (K = 1024; profiles/r04b_direct_bench_*.txt): W.H on 32 x 80 tiles 20.7 / 18.2 / 17.6 us with 2 / 3 / 4 sets,
+    // the H update on 64 x 80 tiles 16.2 / 15.7 (a chunk there is twice as long); K = 128: R.H^T on 16 x 16 tiles 9.8 / 8.9 / 8.3
+    const int depth = gccnmf_tune_direct_depth ? gccnmf_tune_direct_depth : (MB * NB <= 2 ? 4 : 3);
+    if (depth == 2) return direct_launch_n<MB, NB, EPI, 2>(a, stream);
+    if (MB * NB < 20 && depth == 4) return direct_launch_n<MB, NB, EPI, (MB * NB < 20 ? 4 : 3)>(a, stream);
+    return direct_launch_n<MB, NB, EPI, 3>(a, stream);
 }
 
 template <int EPI>

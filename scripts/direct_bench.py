@@ -103,6 +103,15 @@ for t in range(1, 9):
     print('tile %-4s %s' % (TILES[t], sweep[TILES[t]]), flush=True)
 lib.gccnmf_set_tuning(11, 0)
 out['tile_sweep_us'] = sweep
+# register sets of the operand pipeline (tuning key 13), tile by the cost model
+depth = {}
+for dpt in (2, 3, 4):
+    lib.gccnmf_set_tuning(13, dpt)
+    depth[dpt] = {('K1', 'K2', 'K3', 'K4a')[s - 1]: round(time_stage(s, 20), 2) for s in range(1, 5)}
+    depth[dpt]['iteration'] = round(time_iteration(), 2)
+    print('pipeline depth %d: %s' % (dpt, depth[dpt]), flush=True)
+lib.gccnmf_set_tuning(13, 0)
+out['depth_sweep_us'] = depth
 # the whole mixture through the engine
 e.run()
 torch.cuda.synchronize()

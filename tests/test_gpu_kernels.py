@@ -133,7 +133,6 @@ def test_gemm_direct(hip, epi, tile, M, N, Kd, batch, tail, scale):
     """C = A^T . B with both operands reduction-major, against float64; for UPDH `tail` = the rank-1 epilogue term."""
     lib = hip.lib()
     rng = np.random.RandomState(epi * 7919 + tile * 131 + M + N + Kd)
-    Kd16 = -(-Kd // 16) * 16
     Mm = M - 1 if (tail and epi != 3) else M                  # rows on the matrix cores; row M-1 is the VALU tail row
     Kdm = Kd - 1 if (tail and epi == 3) else Kd               # UPDH: the last reduction index is the rank-1 term
     Kd16 = -(-Kdm // 16) * 16
@@ -159,7 +158,7 @@ def test_gemm_direct(hip, epi, tile, M, N, Kd, batch, tail, scale):
     bs = (rng.rand(batch, Kd16) + 0.5).astype(np.float32)
     dbs = dev(bs)
     tailA = np.zeros((batch, Kd16), np.float32)
-    tailA[:, :Kd] = A[:, :, M - 1]
+    tailA[:, :Kdm] = A[:, :Kdm, M - 1]
     dtail = dev(tailA)
     drow = torch.full((batch, N), -7.0, dtype=torch.float32, device='cuda')
     E1 = (rng.rand(batch, M) + 0.5).astype(np.float32)
@@ -405,7 +404,7 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
         torch.cuda.synchronize()
         res[name] = (Wd.cpu().numpy(), Hd.cpu().numpy())
     lib.gccnmf_set_tuning(10, 1)
-    lib.gccnmf_set_tuning(12, 1)
+    lib.gccnmf_set_tuning(12, 4)
     for b in range(B):
         Wr, Hr = O.performKLNMF(V[b], K, 7, 0)
         for name in ('direct-batch', 'ring-batch') + (('split', 'direct') if b == 0 else ()):
@@ -423,8 +422,8 @@ def hip_geometry(F, T, K):
 
 def test_klnmf_batch_is_file_independent(hip):
     """A file's result does not depend on the batch it rides in (XCD-affine map for batch >= 8 included): bit for bit between
-    batches of two or more; a file processed ALONE takes the split-K latency path (reductions cut in four parts, added in a
-    fixed order) and agrees to summation-order accuracy."""
+    batches of the batched kernels; a file processed ALONE or with a few others takes the direct latency path (csrc/direct.hip: the
+    reduction split over the waves of a workgroup, added in a fixed order) and agrees to summation-order accuracy."""
     lib = hip.lib()
     F, T, K, B = 513, 30, 128, 9
     N = 2 * T
@@ -434,7 +433,7 @@ def test_klnmf_batch_is_file_independent(hip):
     V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
     W0, H0 = klnmf_initial_factors(F, N, K)
     outs = []
-    for files in ([0, 3], [5, 8], list(range(B)), [8]):
+    for files in ([0, 3, 1, 2, 4], [5, 8, 7, 6, 2], list(range(B)), [8], [5, 8]):
         b = len(files)
         dV = padded(V[files], (b, g.Fp, g.Np), 'cuda')
         dW = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
@@ -445,7 +444,10 @@ def test_klnmf_batch_is_file_independent(hip):
     assert np.array_equal(outs[0][0][0], outs[2][0][0]) and np.array_equal(outs[0][1][0], outs[2][1][0])
     assert np.array_equal(outs[0][0][1], outs[2][0][3]) and np.array_equal(outs[0][1][1], outs[2][1][3])
     assert np.array_equal(outs[1][0][1], outs[2][0][8]) and np.array_equal(outs[1][1][1], outs[2][1][8])
-    assert rel(outs[3][0][0], outs[2][0][8]) < 2e-6 and rel(outs[3][1][0], outs[2][1][8]) < 2e-6        # alone: split-K
+    assert rel(outs[3][0][0], outs[2][0][8]) < 2e-6 and rel(outs[3][1][0], outs[2][1][8]) < 2e-6        # alone: the direct path
+    assert rel(outs[4][0][1], outs[2][0][8]) < 2e-6 and rel(outs[4][1][0], outs[2][1][5]) < 2e-6        # a pair: the direct path
+    for Wq, Hq in (outs[3], outs[4]):
+        assert not Wq[:, F:, :].any() and not Wq[:, :, K:].any() and not Hq[:, K:, :].any() and not Hq[:, :, N:].any()
     # padding stayed zero
     Wp, Hp = outs[2]
     assert not Wp[:, F:, :].any() and not Wp[:, :, K:].any() and not Hp[:, K:, :].any() and not Hp[:, :, N:].any()
