@@ -30,6 +30,7 @@ int gccnmf_tune_direct = 1;        // key 10: 1 (default) = launches that cannot
 int gccnmf_tune_direct_tile = 0;   // key 11: 0 = tile by the cost model, 1..8 = that tile for every direct launch (experiments)
 int gccnmf_tune_direct_batch = 4;  // key 12: largest batch that takes the direct path (measured, K = 1024: 4 files 21.8 ms against 25.8 on the ring
                                    // kernel, 8 files 41.5 / 41.3, 12 files 61.9 / 59.3)
+int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
 int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
@@ -72,6 +73,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 11 && value >= 0 && value <= 8) {
         gccnmf_tune_direct_tile = value;
+        return GCCNMF_OK;
+    }
+    if (key == 14 && (value == 0 || value == 1)) {
+        gccnmf_tune_short_updh = value;
         return GCCNMF_OK;
     }
     if (key == 13 && (value == 0 || (value >= 2 && value <= 4))) {
@@ -408,7 +413,11 @@ static bool small_batch_tile(const GemmArgs& a) {
 template <bool A_KC, bool B_KC, int EPI>
 static int dispatch_gemm(const GemmArgs& a, bool tail, hipStream_t s) {
     const bool tall = a.M > 128;
-    if (small_batch_tile(a) && gccnmf_tune_ring && gccnmf_ring_supports(a.Kd)) {   // (longer reductions: the register-staged tile below)
+    // The H update of a SMALL dictionary (K <= 128 atoms = output rows: the reference driver's default, runGCCNMF.py:41) used to ride the
+    // register-staged wide tile (128 x 256 per workgroup, one k-tile prefetched): 154 us per launch for 64 files at K = 128 = 0.43 of the
+    // matrix peak.  The LDS-DMA ring kernel's 128 x 64 tiles (six stages in flight, image-layout epilogue) take it instead (key 14).
+    const bool short_updh = !tall && EPI == EPI_UPDH && gccnmf_tune_short_updh && gccnmf_tune_tile_policy != 1 && a.N >= 256;
+    if ((small_batch_tile(a) || short_updh) && gccnmf_tune_ring && gccnmf_ring_supports(a.Kd)) {   // (longer reductions: the register-staged tile below)
         if (A_KC) return tail ? gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, A_KC>(a, s) : gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);
         if (tail) return GCCNMF_ERR_ARG;
         return gccnmf_launch_gemm_ring<A_KC, B_KC, EPI, false>(a, s);

@@ -17,7 +17,8 @@ from gcc_nmf_amd.synthetic import synthetic_batch       # noqa: E402
 lib = _hip.lib()
 xs = synthetic_batch(0, 1)
 K = int(os.environ.get('K', '1024'))
-e = GCCNMFEngine(160000, dictionarySize=K, numIterations=100, batch=1)
+HOP = int(os.environ.get('HOP', '256'))             # K=128 HOP=128: the reference driver's own call (runGCCNMF.py:41,60)
+e = GCCNMFEngine(160000, dictionarySize=K, numIterations=100, batch=1, hopSize=HOP)
 e.upload(xs[0])
 
 
@@ -46,8 +47,12 @@ for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE
 if '--profile' in sys.argv:
     run('default', 2)
     sys.exit(0)
+lib.gccnmf_set_tuning(10, 1)
+y_new = run('direct path (round 4)')
+lib.gccnmf_set_tuning(10, 0)
 lib.gccnmf_set_tuning(4, 0)
 y_old = run('register-staged (round 1)')
+print('    waveform rms direct vs register-staged: %.2e' % float(((y_new - y_old) ** 2).mean().sqrt()))
 lib.gccnmf_set_tuning(4, 1)
 for wh in (2, 3, 4):
     for rht in (4,):
