@@ -7,7 +7,24 @@
 // same soname) keeps using that one instance; a host without RCCL can still load libgccnmf_hip.so for single-GPU work.
 #include <dlfcn.h>
 #include <mutex>
+#include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// building without the RCCL headers: the handful of declarations this file binds at run time (ABI of librccl.so.1 / nccl.h)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream);
+}
+#endif
 #include "common.h"
 #include "../../include/gccnmf_hip.h"
 

@@ -879,7 +879,7 @@ static int shared_begin(const SharedShard* sh, int n, const float* W, float* col
 }
 
 // Side streams of the shared-dictionary iteration.  K1 .. K4a of different files (column blocks) are independent until the W update,
-// so a rank's files run as up to GCCNMF_SHARED_STREAMS groups on separate streams (tuning key 8, default 2): the tail of one group's
+// so a rank's files run as up to GCCNMF_SHARED_STREAMS groups on separate streams (tuning key 8, default 3): the tail of one group's
 // launch -- when its last workgroups no longer fill both slots of every CU -- overlaps the head of another group's, exactly as the
 // per-file-dictionary engine does with its file groups.  Same kernels on the same data: bitwise the one-stream result.
 struct SidePool {
@@ -919,9 +919,12 @@ static SharedShard sub_shard(const SharedShard& sh, int b0, int b1) {
 
 // H update with the current W, then the per-file (V/WH).H^T and row sums of H (K1, K2, K3, K4a on stream s)
 static int shared_gemms(const SharedShard& sh, const float* W, const float* colsumW, const float* hscale, float alpha, float eps,
-                        hipStream_t s) {
+                        bool beside_others, hipStream_t s) {
     const NmfGeom& g = sh.g;
     int rc;
+    // bit 1 = another unit's launches run beside these on a side stream: the tile-layout cost model of gemm_dma.h prices a launch that
+    // has the chip to itself, so such units keep full tiles (their partial rounds overlap the neighbours' kernels)
+    const int xcd = 1 | (beside_others ? 2 : 0);
     if (sh.latency) {                           // one file alone: the split-K launches of the latency path
         if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, hscale, sh.parts, sh.R, s))) return rc;
         if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, 1, 0, s))) return rc;
@@ -930,11 +933,11 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
     }
     // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
     // through that XCD's L2), exactly as the per-file-dictionary path does
-    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, hscale, 0, sh.R, sh.batch, 1, s))) return rc;
-    if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, sh.batch, 1, s))) return rc;
+    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, hscale, 0, sh.R, sh.batch, xcd, s))) return rc;
+    if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, sh.batch, xcd, s))) return rc;
     // (H now carries the previous normalisation; K3 below takes no scale, and step B rewrites hscale before anyone reads it again)
-    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, nullptr, 0, sh.R, sh.batch, 1, s))) return rc;
-    return launch_rht(g, sh.R, sh.H, sh.Upart, sh.rowsum_part, sh.batch, 1, s);
+    if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, nullptr, 0, sh.R, sh.batch, xcd, s))) return rc;
+    return launch_rht(g, sh.R, sh.H, sh.Upart, sh.rowsum_part, sh.batch, xcd, s);
 }
 
 // partial (+)= [sum_files Upart || sum_files rowsum_part], files in ascending order (deterministic)
@@ -980,7 +983,7 @@ static int shared_step_a_all(const SharedShard* sh, int n, const float* W, const
     }
     for (int u = 0; u < nu; ++u) {
         const int l = u % lanes;
-        if ((rc = shared_gemms(units[u], W, colsumW, hscale, alpha, eps, l ? pool->side[l - 1] : s))) return rc;
+        if ((rc = shared_gemms(units[u], W, colsumW, hscale, alpha, eps, lanes > 1, l ? pool->side[l - 1] : s))) return rc;
     }
     for (int l = 1; l < lanes; ++l) {
         if (hipEventRecord(pool->join[l - 1], pool->side[l - 1]) != hipSuccess) return GCCNMF_ERR_LAUNCH;
@@ -1062,11 +1065,31 @@ int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, 
 
 // The whole shared-dictionary training of one rank in ONE call: begin, `iterations` x (step A of every shard -> all-reduce of
 // `partial` -> step B), finish -- every launch and the collective enqueued on `stream` from C, no host round trip per iteration.
+// One training at a time per device: the side streams and events of shared_step_a_all are per-device library state.  A second call that
+// arrives while one is still enqueueing is REJECTED (GCCNMF_ERR_UNSUPPORTED) instead of racing on them.
+namespace {
+std::atomic<int> shared_run_busy[GCCNMF_MAX_DEVICES];
+struct SharedRunGuard {
+    int dev = -1;
+    bool held = false;
+    SharedRunGuard() {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GCCNMF_MAX_DEVICES) { dev = -1; held = true; return; }
+        int expected = 0;
+        held = shared_run_busy[dev].compare_exchange_strong(expected, 1);
+    }
+    ~SharedRunGuard() {
+        if (held && dev >= 0) shared_run_busy[dev].store(0);
+    }
+};
+}  // namespace
+
 int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, float* W, float* partial, float* vec, int F, int K,
                             int iterations, float sparsity_alpha, float epsilon, gccnmf_allreduce_fn allreduce, void* allreduce_ctx,
                             void* stream) {
     if (nshards < 0 || nshards > GCCNMF_MAX_SHARDS || (nshards && !shards) || !W || !partial || !vec || F < 2 || K < 1 || iterations < 0)
         return GCCNMF_ERR_ARG;
+    SharedRunGuard guard;
+    if (!guard.held) return GCCNMF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     SharedShard sh[GCCNMF_MAX_SHARDS];
     for (int i = 0; i < nshards; ++i) {

@@ -62,14 +62,59 @@ def shared_initial_factors(F, file_columns, K, file_indexes, epsilon=1e-16, seed
 _rccl_comms = {}
 
 
+def _default_group():
+    """The process group object behind group=None (a re-initialised default group is a NEW object: its communicator is not reused)."""
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:
+        return dist.group.WORLD
+
+
+def _ipc_env_note():
+    """'' when the environment allows RCCL between processes on this driver stack, else what is wrong with it."""
+    import os
+    v = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
+    if v == '0':
+        return ''
+    return ('HSA_ENABLE_IPC_MODE_LEGACY is %s in this process (it must be 0 BEFORE the HIP runtime starts: the host driver only supports '
+            'dmabuf IPC, RCCL otherwise fails with hipIpcGetMemHandle: invalid argument)' % ('unset' if v is None else repr(v)))
+
+
+def _call_with_timeout(fn, seconds, what):
+    """fn() on a helper thread; HipLibraryError if it has not returned after `seconds` (a collective whose peers never arrive
+    blocks forever inside librccl: the caller gets an explanation instead of a silent hang; the stuck thread is left behind)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box['value'] = fn()
+        except BaseException as e:            # noqa: B902 -- re-raised on the caller's thread
+            box['error'] = e
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        note = _ipc_env_note()
+        raise _hip.HipLibraryError('%s did not return within %.0f s: a peer rank never arrived or RCCL cannot reach it over xGMI%s.  '
+                                   'GCCNMF_COLLECTIVE=torch routes the all-reduce through torch.distributed instead; '
+                                   'GCCNMF_RCCL_INIT_TIMEOUT sets this limit.' % (what, seconds, ('; ' + note) if note else ''))
+    if 'error' in box:
+        raise box['error']
+    return box['value']
+
+
 def _rccl_comm(group, device):
     """The library-owned RCCL communicator of (group, device), or None when RCCL cannot be used on EVERY rank."""
     import ctypes
-    key = (group if group is not None else 'world', torch.device(device).index)      # the group object itself: no id() reuse after a destroy
-    if key in _rccl_comms:
-        return _rccl_comms[key]
-    lib = _hip.lib()
+    import os
+    gobj = group if group is not None else _default_group()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    key = (gobj, torch.device(device).index)           # the group object itself: no id() reuse after a destroy, no stale default group
+    hit = _rccl_comms.get(key)
+    if hit is not None and hit[1:] == (world, rank):
+        return hit[0]
+    lib = _hip.lib()
     src = dist.get_global_rank(group, 0) if group is not None else 0
     ident = torch.zeros(_hip.RCCL_UNIQUE_ID_BYTES + 1, dtype=torch.uint8, device=device)     # [id bytes | ok flag]
     if rank == 0 and lib.gccnmf_rccl_available():
@@ -85,31 +130,40 @@ def _rccl_comm(group, device):
     if int(flag.item()):
         handle = ctypes.c_void_p()
         torch.cuda.synchronize(device)
-        with torch.cuda.device(device):
-            ok = lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
+        timeout = float(os.environ.get('GCCNMF_RCCL_INIT_TIMEOUT', '120'))
+
+        def init():
+            with torch.cuda.device(device):
+                return lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
+        ok = _call_with_timeout(init, timeout, 'gccnmf_rccl_comm_init (rank %d of %d, device %s)' % (rank, world, device))
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()):
             comm = handle.value
         elif ok:
             lib.gccnmf_rccl_comm_destroy(handle)
-    _rccl_comms[key] = comm
+    _rccl_comms[key] = (comm, world, rank)
     return comm
 
 
 def destroy_rccl_communicators():
     """Free the library-owned communicators (call before dist.destroy_process_group())."""
-    for comm in _rccl_comms.values():
+    for comm, _, _ in _rccl_comms.values():
         if comm:
             _hip.lib().gccnmf_rccl_comm_destroy(comm)
     _rccl_comms.clear()
 
 
-def collective_hook(partial, group=None):
-    """(function pointer, context, keep-alive, description) for gccnmf_klnmf_shared_run's all-reduce of ``partial``."""
+def collective_hook(partial, group=None, force=False):
+    """(function pointer, context, keep-alive, description) for gccnmf_klnmf_shared_run's all-reduce of ``partial``.
+
+    nccl backend: the library's own RCCL communicator, enqueued from C (GCCNMF_COLLECTIVE=torch: a host callback into
+    torch.distributed instead; =rccl: RCCL or an error).  Any other backend: the host callback.  A single rank needs no exchange;
+    ``force`` (or GCCNMF_COLLECTIVE_FORCE=1) builds the hook anyway, so that a one-GPU box drives the same call path."""
     import ctypes
     import os
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    force = force or os.environ.get('GCCNMF_COLLECTIVE_FORCE', '') not in ('', '0')
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)):
         return None, None, None, 'single rank'
     want = os.environ.get('GCCNMF_COLLECTIVE', '')
     if want not in ('', 'rccl', 'torch'):
@@ -119,7 +173,7 @@ def collective_hook(partial, group=None):
         if comm:
             return _hip.lib().gccnmf_rccl_allreduce_hook(), comm, None, 'rccl (library communicator, enqueued from C)'
         if want == 'rccl':
-            raise _hip.HipLibraryError('GCCNMF_COLLECTIVE=rccl but librccl could not be bound / initialised on every rank')
+            raise _hip.HipLibraryError('GCCNMF_COLLECTIVE=rccl but librccl could not be bound / initialised on every rank.  ' + _ipc_env_note())
     failure = []
 
     def allreduce(ctx, buf, count, stream):

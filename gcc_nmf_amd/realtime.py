@@ -119,6 +119,7 @@ class GCCNMFProcessor(object):
         self.dTarget = part(4, 4)
         self.dTarget.copy_(torch.from_numpy(self._target_host))
         self._mirror_offs, self._mirror_sizes, self._mirror_host = offs, sizes, None
+        self._calls, self._target_seen, self._target_value, self._target_pin = 0, -1, float(self._target_host[0]), None
         self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
 
     @_on_device
@@ -126,13 +127,27 @@ class GCCNMFProcessor(object):
         """:272-275"""
         self._target_host = np.array([targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor], np.float32)
         self.dTarget.copy_(torch.from_numpy(self._target_host))
+        self._target_value, self._target_seen = float(self._target_host[0]), self._calls
 
     @property
     def targetTDOAIndex(self):
-        return float(self.dTarget[0].item())
+        """The tracked target TDOA index.  Only the online localisation (csrc/rt.hip) changes it on the device; without it the host copy
+        set by setTargetTDOARange IS the value.  With it, the value of the last device call is fetched at most once per call (from the
+        history mirror when that was downloaded anyway, else one 16-byte page-locked copy) -- repeated reads never touch the device."""
+        if not self.localizationEnabled:
+            return float(self._target_host[0])
+        if self._target_seen != self._calls:
+            if self._target_pin is None:
+                self._target_pin = torch.zeros(4, dtype=torch.float32).pin_memory()
+            with torch.cuda.device(self.device):
+                self._target_pin.copy_(self.dTarget, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            self._target_value, self._target_seen = float(self._target_pin[0]), self._calls
+        return self._target_value
 
     @_on_device
     def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode, out_delay_blocks=2):
+        self._calls += 1
         _hip.check(self.lib.gccnmf_rt_process_block_ll(
             _ptr(block_in), _ptr(block_out), _ptr(in_ring), _ptr(out_ring), _ptr(self.dX), _ptr(self.dY), _ptr(self.dC), _ptr(self.dHMask),
             _ptr(self.dArgmax), _ptr(self.dTfMask), _ptr(self.dHist), _ptr(self.dHistPos), _ptr(self.dTarget), _ptr(self.dGccPhat),
@@ -172,6 +187,7 @@ class GCCNMFProcessor(object):
         self._mirror_host.copy_(self.dMirror, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         m, o, n = self._mirror_host.numpy(), self._mirror_offs, self._mirror_sizes
+        self._target_value, self._target_seen = float(m[o[4]]), self._calls              # the tracked index came along
         F, Tc, K, D = self.numFrequencies, self.numTimePerChunk, self.numAtom, self.numTDOAs
         cplx = lambda i: m[o[i]:o[i] + n[i]].reshape(2, F, Tc, 2).copy().view(np.complex64)[..., 0]
         X = cplx(0)
@@ -205,6 +221,7 @@ class StreamingGCCNMF(object):
 
     def __init__(self, processor, hopSize, blockSize, outputDelayBlocks=2, use_graph=True):
         self.use_graph = bool(use_graph)
+        self.capture_error = None          # the exception of a failed HIP-graph capture (process_block then launches directly)
         # outputDelayBlocks: 2 = the reference's hand-out (utils.py:116); 1 is complete when the synthesis window spans two hops
         if outputDelayBlocks not in (1, 2, 3, 4, 5, 6, 7):
             raise ValueError('outputDelayBlocks must be 1..7')

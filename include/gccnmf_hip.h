@@ -56,7 +56,12 @@ int gccnmf_version(void);
  * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
  * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
  * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout
- * (bitwise the same results in every form); 0 = always full tiles; 2 = always half-height (experiments).  Unknown keys / values: GCCNMF_ERR_ARG. */
+ * (bitwise the same results in every form); 0 = always full tiles; 2 = always half-height (experiments).
+ * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
+ * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
+ * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..16, default 4).
+ * key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4).  key 14: 1 (default) = H updates of at most 128
+ * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -152,7 +157,8 @@ int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, 
  * allreduce: sums `count` floats of `buf` (device memory) in place over all ranks, ordered on `stream`; returns 0 on success.
  *   NULL = single rank.  Not re-entrant per device: the file groups of a shard that cannot fill the chip run on side streams and
  *   events the library owns, one set per device (tuning key 8) -- one training at a time per device, like the reference's
- *   single-threaded caller.  gccnmf_rccl_allreduce below is the RCCL implementation; any other transport (MPI, a host callback that
+ *   single-threaded caller.  ENFORCED: a call that arrives while another thread is still inside this function for the same device
+ *   returns GCCNMF_ERR_UNSUPPORTED without launching anything.  gccnmf_rccl_allreduce below is the RCCL implementation; any other transport (MPI, a host callback that
  *   runs torch.distributed over gloo ...) has the same signature. */
 #define GCCNMF_MAX_SHARDS 8
 typedef struct gccnmf_shared_shard {

@@ -25,9 +25,15 @@ def main(out_dir, F, K, N, B, iters, init='concat'):
     import torch.distributed as dist
     from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, shard_files, train_shared_dictionary
     import datetime
-    dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))      # a failed rank must not park the others for half an hour
+    backend = os.environ.get('GCCNMF_WORKER_BACKEND', 'gloo')                     # nccl: one rank per GPU, the library's RCCL communicator
+    if backend == 'nccl':
+        local_rank = int(os.environ['LOCAL_RANK'])
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=180), device_id=torch.device('cuda', local_rank))
+    else:
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))      # a failed rank must not park the others for half an hour
+        torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
     mine = shard_files(B, world, rank)
     V = problem(F, [N] * B, 11, mine)
     W0, H0 = shared_initial_factors(F, [N] * B, K, mine, mode=init)
@@ -38,6 +44,8 @@ def main(out_dir, F, K, N, B, iters, init='concat'):
     with open(os.path.join(out_dir, 'collective_rank%d.txt' % rank), 'w') as f:
         f.write(local.collective)
     dist.barrier()
+    from gcc_nmf_amd.distributed import destroy_rccl_communicators
+    destroy_rccl_communicators()
     dist.destroy_process_group()
 
 

@@ -194,3 +194,28 @@ def test_allreduce_hook_is_a_host_callback_over_gloo(tmp_path):
     mp.spawn(_hook_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / ('hook_rank%d.npy' % r)), np.full(1000, 3.0, np.float32))
+
+
+def test_collective_timeout_and_ipc_environment_messages(monkeypatch):
+    """A collective set-up that never returns surfaces as a HipLibraryError that says what to check (ADVICE r3 / VERDICT r3 #4c), and the
+    package sets the dmabuf-IPC switch RCCL needs on this driver stack unless the user chose a value."""
+    import time
+    import gcc_nmf_amd                                   # noqa: F401  (import sets the default)
+    from gcc_nmf_amd import _hip, distributed as D
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') is not None
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert D._ipc_env_note() == ''
+    assert D._call_with_timeout(lambda: 41 + 1, 5, 'quick') == 42
+    with pytest.raises(ValueError):
+        D._call_with_timeout(lambda: (_ for _ in ()).throw(ValueError('boom')), 5, 'raises')
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '1')
+    assert 'HSA_ENABLE_IPC_MODE_LEGACY' in D._ipc_env_note()
+    t0 = time.time()
+    with pytest.raises(_hip.HipLibraryError) as e:
+        D._call_with_timeout(lambda: time.sleep(30), 0.2, 'gccnmf_rccl_comm_init (rank 1 of 2, device cuda:1)')
+    assert time.time() - t0 < 5
+    msg = str(e.value)
+    assert 'gccnmf_rccl_comm_init' in msg and 'GCCNMF_COLLECTIVE=torch' in msg and 'HSA_ENABLE_IPC_MODE_LEGACY' in msg
+    # a single process (no group) needs no exchange; an unknown route is an error only once a group exists
+    hook = D.collective_hook(None)
+    assert hook[0] is None and hook[3] == 'single rank'

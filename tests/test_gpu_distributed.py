@@ -217,6 +217,102 @@ def test_rccl_single_rank_group():
         dist.destroy_process_group()
 
 
+def test_forced_hook_on_a_one_rank_nccl_group_rccl_and_torch_paths():
+    """One GPU is enough to drive BOTH all-reduce routes of the nccl backend end to end (GCCNMF_COLLECTIVE_FORCE=1 builds the hook for a
+    single rank): the library's own RCCL communicator created through the process group (unique id broadcast, init agreed on by
+    MIN all-reduces, ncclAllReduce enqueued from C), and GCCNMF_COLLECTIVE=torch, the host callback into torch.distributed."""
+    import torch.distributed as dist
+    from gcc_nmf_amd import distributed as D
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    saved = {k: os.environ.get(k) for k in ('GCCNMF_COLLECTIVE', 'GCCNMF_COLLECTIVE_FORCE')}
+    try:
+        F, K, N, B = 129, 32, 40, 2
+        V = _problem(F, K, [N] * B, seed=5)
+        W0, H0 = D.shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+        os.environ['GCCNMF_COLLECTIVE_FORCE'] = '1'
+        os.environ.pop('GCCNMF_COLLECTIVE', None)
+        a = D.train_shared_dictionary(D.HipSharedNMF(V, W0, H0), 5)
+        assert a.collective.startswith('rccl'), a.collective
+        os.environ['GCCNMF_COLLECTIVE'] = 'torch'
+        b = D.train_shared_dictionary(D.HipSharedNMF(V, W0, H0), 5)
+        assert b.collective.startswith('torch.distributed (nccl)'), b.collective
+        os.environ.pop('GCCNMF_COLLECTIVE_FORCE')
+        c = D.train_shared_dictionary(D.HipSharedNMF(V, W0, H0), 5)
+        assert c.collective == 'single rank'
+        assert np.array_equal(a.W(), c.W()) and np.array_equal(b.W(), c.W())          # a sum over one rank changes nothing
+        Wr, _ = O.performKLNMF(np.concatenate(V, axis=1), K, 5, 0)
+        assert np.linalg.norm(c.W() - Wr) < 1e-4 * np.linalg.norm(Wr)
+        # a re-initialised default group gets a NEW communicator (the cache is keyed by the group object)
+        assert len(D._rccl_comms) == 1
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        D.destroy_rccl_communicators()
+        dist.destroy_process_group()
+
+
+def test_two_gpus_library_rccl_between_devices(tmp_path):
+    """ncclAllReduce between two DEVICES through the library's communicator (skipped on a one-GPU box): W identical on both ranks and
+    equal to the single-process result."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import sys
+    from conftest import REPO
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from shared_rank_worker import problem
+    F, K, N, B, iters = 513, 256, 128, 6, 8
+    os.environ['GCCNMF_WORKER_BACKEND'] = 'nccl'
+    try:
+        _run_ranks(2, 'shared_rank_worker.py', [tmp_path, F, K, N, B, iters])
+    finally:
+        os.environ.pop('GCCNMF_WORKER_BACKEND')
+    W = [np.load(tmp_path / ('W_rank%d.npy' % i)) for i in range(2)]
+    assert np.array_equal(W[0], W[1])
+    assert open(tmp_path / 'collective_rank1.txt').read().startswith('rccl')
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    one = train_shared_dictionary(HipSharedNMF(problem(F, [N] * B, 11), W0, H0), iters)
+    assert np.linalg.norm(W[0] - one.W()) < 1e-5 * np.linalg.norm(one.W())
+
+
+def test_shared_run_rejects_a_second_call_on_the_same_device():
+    """gccnmf_klnmf_shared_run owns per-device side streams: a call that arrives while another is inside (here: from the all-reduce
+    callback of the first) is rejected with GCCNMF_ERR_UNSUPPORTED instead of racing."""
+    import ctypes
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors
+    from gcc_nmf_amd.engine import _ptr, _stream
+    lib = _hip.lib()
+    F, K, N, B = 129, 32, 40, 2
+    V = _problem(F, K, [N] * B, seed=5)
+    W0, H0 = shared_initial_factors(F, [N] * B, K, range(B), mode='concat')
+    local = HipSharedNMF(V, W0, H0)
+    descs = local._shards()
+    arr = (_hip.SharedShard * len(descs))()
+    for d, (Vd, Hd, ws, n, batch, ld) in zip(arr, descs):
+        d.V, d.H, d.workspace, d.N, d.batch, d.ld = _ptr(Vd), _ptr(Hd), _ptr(ws), n, batch, ld
+    seen = []
+
+    def hook(ctx, buf, count, stream):
+        seen.append(lib.gccnmf_klnmf_shared_run(arr, len(descs), _ptr(local.Wd), _ptr(local.partial), _ptr(local.vec), F, K, 1, 0.0, 1e-16,
+                                                None, None, _stream()))
+        return 0
+    cb = _hip.ALLREDUCE_FN(hook)
+    rc = lib.gccnmf_klnmf_shared_run(arr, len(descs), _ptr(local.Wd), _ptr(local.partial), _ptr(local.vec), F, K, 2, 0.0, 1e-16,
+                                     ctypes.cast(cb, ctypes.c_void_p).value, None, _stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and seen == [3, 3]                      # GCCNMF_ERR_UNSUPPORTED, twice (once per iteration)
+    assert lib.gccnmf_klnmf_shared_run(arr, len(descs), _ptr(local.Wd), _ptr(local.partial), _ptr(local.vec), F, K, 1, 0.0, 1e-16, None, None,
+                                       _stream()) == 0        # and the guard is released afterwards
+
+
 def test_pretraining_cache_roundtrip(tmp_path):
     """Reference-format dictionary cache (data/pretrainedW/W_<K>.npy, float32 (F,K)) trained on the GPU from the mixtures in
     DATA_DIR; second load hits the cache; dictionaries agree with the oracle trained on the same matrix."""
