@@ -31,7 +31,13 @@ typedef __attribute__((address_space(1))) const void* gemm_glb_ptr;
 // One LDS-DMA piece: 16 B per lane from (wave-uniform base, SGPR pair) + (unsigned 32-bit per-lane byte offset); lane l lands at
 // M0 + 16*l, M0 = LDS byte address of the piece (wave-uniform).  Inline asm: for __builtin_amdgcn_global_load_lds hipcc does
 // not select this `saddr + voffset` form -- it adds base + offset on the VALU before every piece and keeps the offsets as
-// 64-bit pairs.  (M0 is written without being declared: nothing else in these kernels uses it.)
+// 64-bit pairs.
+// M0: the statement that reads it also writes it, first thing -- so it never depends on what the compiler left there.  It cannot be
+// DECLARED as clobbered: M0 is a compiler-reserved register on AMDGPU, a "m0" clobber only draws `warning: inline asm clobber list
+// contains reserved registers: m0 ... may not be preserved across the asm statement` and changes nothing (checked with hipcc 7.2; the
+// CDNA HIP guide's section on inline asm says the same: "Write M0 in the SAME statement that reads it").  The compiler's own uses of M0
+// (LDS-DMA builtins, ds_gws / s_sendmsg, indirect register indexing) re-materialise it immediately before each use for the same reason,
+// and these kernels contain none of them; tests/test_host.py::test_lds_dma_statements_set_m0_themselves keeps it that way.
 __device__ __forceinline__ void gemm_dma16(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
                  :

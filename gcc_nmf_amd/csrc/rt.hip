@@ -21,27 +21,33 @@ typedef float rt_f32x16 __attribute__((ext_vector_type(16)));
 // ---- rt_shift: single workgroup, in-place left shift by B of both 8-block buffers ---------------------------
 __global__ __launch_bounds__(1024) void rt_shift_kernel(float* __restrict__ in_ring, float* __restrict__ out_ring,
                                                         const float* __restrict__ block_in, int B, int ring) {
-    // ring = 8*B samples per channel, 2 channels; every thread first loads everything it will store
+    // ring = 8*B samples per channel, 2 channels.  Chunks of 8192 values in ascending order, every thread loading everything it
+    // will store before the barrier: a chunk reads at or above the positions it writes (never below), so no later chunk's stores can
+    // reach what an earlier one still has to read -- any block size, one workgroup (the reference's buffers have no size limit,
+    // realtime/utils.py:72-97).
     const int total = 2 * ring;
-    float vin[8], vout[8];
+    for (int base = 0; base < total; base += 8192) {
+        float vin[8], vout[8];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int i = threadIdx.x + 1024 * n;
-        vin[n] = vout[n] = 0.f;
-        if (i < total) {
-            const int c = i / ring, s = i - c * ring;
-            vin[n] = (s + B < ring) ? in_ring[c * ring + s + B] : block_in[c * B + (s + B - ring)];
-            vout[n] = (s + B < ring) ? out_ring[c * ring + s + B] : 0.f;
+        for (int n = 0; n < 8; ++n) {
+            const int i = base + threadIdx.x + 1024 * n;
+            vin[n] = vout[n] = 0.f;
+            if (i < total) {
+                const int c = i / ring, s = i - c * ring;
+                vin[n] = (s + B < ring) ? in_ring[c * ring + s + B] : block_in[c * B + (s + B - ring)];
+                vout[n] = (s + B < ring) ? out_ring[c * ring + s + B] : 0.f;
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const int i = threadIdx.x + 1024 * n;
-        if (i < total) {
-            in_ring[i] = vin[n];
-            out_ring[i] = vout[n];
+        for (int n = 0; n < 8; ++n) {
+            const int i = base + threadIdx.x + 1024 * n;
+            if (i < total) {
+                in_ring[i] = vin[n];
+                out_ring[i] = vout[n];
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -251,6 +257,116 @@ __global__ __launch_bounds__(FFT_NT) void rt_synth_kernel(const float2* __restri
     for (int i = threadIdx.x; i < 2 * B; i += FFT_NT) {
         const int c = i / B, s = i - c * B;
         block_out[i] = out_ring[c * ring + ring - (out_delay + 1) * B + s];           // utils.py:116 (out_delay = 2 there)
+    }
+}
+
+// ---- any even window size (the reference takes every windowSize: numpy.fft.rfft / irfft, gccNMFProcessor.py:202,:231) -------------
+// Off the powers of two the transform is evaluated as the sum it is, against a full-circle table (cos, sin)(2 pi k / N), k < N, computed
+// in float64 on the host: a frame is 2 x (N/2 + 1) x N complex MACs (N = 1000: 4 MFLOP) -- nothing on this chip, and no mixed-radix
+// machinery for a path whose defaults are powers of two.  The angle index f * n mod N advances by one addition and one compare.
+// rt_frames_dft: grid = (ceil(F / 64), Tc), 256 threads = 64 frequencies x 4 segments of n (partial sums added in segment order).
+__global__ __launch_bounds__(256) void rt_frames_dft_kernel(const float* __restrict__ in_ring, int ring, int N, int start0, int start_step,
+                                                            int Tc, const float* __restrict__ window, const float2* __restrict__ table,
+                                                            float2* __restrict__ X, float2* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) float2 rt_smem[];
+    float2* xw = rt_smem;                  // windowed samples (left, right)
+    float2* tb = rt_smem + N;
+    __shared__ float4 s_part[4][64];
+    const int t = blockIdx.y, F = N / 2 + 1;
+    const int start = start0 + t * start_step;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float w = window[n];
+        xw[n] = make_float2(w * in_ring[start + n], w * in_ring[ring + start + n]);
+        tb[n] = table[n];
+    }
+    __syncthreads();
+    const int fl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int f = min(blockIdx.x * 64 + fl, F - 1);
+    const int n0 = (int)(((long)N * seg) / 4), n1 = (int)(((long)N * (seg + 1)) / 4);
+    int idx = (int)(((long)f * n0) % N);
+    float reL = 0.f, imL = 0.f, reR = 0.f, imR = 0.f;
+    for (int n = n0; n < n1; ++n) {
+        const float2 c = tb[idx], x = xw[n];           // e^{-j theta} = cos - j sin (rfft, NOT conjugated, :202)
+        reL = fmaf(x.x, c.x, reL); imL = fmaf(-x.x, c.y, imL);
+        reR = fmaf(x.y, c.x, reR); imR = fmaf(-x.y, c.y, imR);
+        idx += f;
+        if (idx >= N) idx -= N;
+    }
+    s_part[seg][fl] = make_float4(reL, imL, reR, imR);
+    __syncthreads();
+    if (seg == 0 && blockIdx.x * 64 + fl < F) {
+        float4 a = s_part[0][fl];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 b = s_part[q][fl];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const float2 XL = make_float2(a.x, a.y), XR = make_float2(a.z, a.w);
+        X[(long)f * Tc + t] = XL;
+        X[((long)F + f) * Tc + t] = XR;
+        const float aL = hypotf(XL.x, XL.y), aR = hypotf(XR.x, XR.y);
+        const float re = XL.x * XR.x + XL.y * XR.y, im = XL.y * XR.x - XL.x * XR.y;
+        C[(long)f * Tc + t] = make_float2(re / aL / aR, im / aL / aR);                   // 0/0 -> NaN like the reference (:253)
+    }
+}
+
+// rt_synth_dft: one thread per OUTPUT position of the buffer (both channels), frames in ascending order -- the reference's accumulation
+// order (utils.py:113-114), and no two threads ever add into the same sample.  grid = ceil(positions / 256); s_lo = first position.
+__global__ __launch_bounds__(256) void rt_synth_dft_kernel(const float2* __restrict__ Y, int N, int start0, int start_step, int accumulate,
+                                                           int Tc, int ring, int B, int out_delay, int s_lo, const float* __restrict__ window,
+                                                           const float2* __restrict__ table, float* __restrict__ out_ring,
+                                                           float* __restrict__ block_out) {
+    extern __shared__ __attribute__((aligned(16))) float2 rt_smem[];
+    float2* tb = rt_smem;                  // [N]
+    float2* ya = rt_smem + N;              // [F] left
+    float2* yb = ya + (N / 2 + 1);         // [F] right
+    const int F = N / 2 + 1, H = N / 2;
+    const float invN = 1.f / (float)N;
+    const int s = s_lo + blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < ring;
+    for (int n = threadIdx.x; n < N; n += 256) tb[n] = table[n];
+    float va = 0.f, vb = 0.f;
+    if (live && accumulate) {
+        va = out_ring[s];
+        vb = out_ring[ring + s];
+    }
+    for (int t = 0; t < Tc; ++t) {
+        __syncthreads();
+        for (int f = threadIdx.x; f < F; f += 256) {
+            float2 a = Y[(long)f * Tc + t], b = Y[((long)F + f) * Tc + t];
+            if (f == 0 || f == H) {          // numpy.fft.irfft ignores the imaginary part of DC and Nyquist
+                a.y = 0.f;
+                b.y = 0.f;
+            }
+            ya[f] = a;
+            yb[f] = b;
+        }
+        __syncthreads();
+        const int n = s - (start0 + t * start_step);
+        if (live && n >= 0 && n < N) {
+            const float sign = (n & 1) ? -1.f : 1.f;
+            float sa = 0.f, sb = 0.f;
+            int idx = n;                                   // f * n mod N for f = 1
+            for (int f = 1; f < H; ++f) {
+                const float2 c = tb[idx], a = ya[f], b = yb[f];
+                sa = fmaf(a.x, c.x, fmaf(-a.y, c.y, sa));
+                sb = fmaf(b.x, c.x, fmaf(-b.y, c.y, sb));
+                idx += n;
+                if (idx >= N) idx -= N;
+            }
+            const float w = window[n];
+            const float fa = w * ((ya[0].x + sign * ya[H].x + 2.f * sa) * invN), fb = w * ((yb[0].x + sign * yb[H].x + 2.f * sb) * invN);
+            va = accumulate ? va + fa : fa;
+            vb = accumulate ? vb + fb : fb;
+        }
+    }
+    if (!live) return;
+    out_ring[s] = va;
+    out_ring[ring + s] = vb;
+    const int h0 = ring - (out_delay + 1) * B;           // utils.py:116 (out_delay = 2 there)
+    if (accumulate && s >= h0 && s < h0 + B) {
+        block_out[s - h0] = va;
+        block_out[B + s - h0] = vb;
     }
 }
 
@@ -468,17 +584,20 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
     // (2 then 4 = the same work in two calls, so that a host can fetch block_out before the tracking update has run)
     const int frames_mode = frames_mode_bits & 1;
     const bool skip_localize = frames_mode_bits & 2, only_localize = frames_mode_bits & 4;
-    const int logN = ilog2_exact(windowSize);
+    // powers of two from 64 up: the radix-2 LDS transform (twiddle = N/2 values of exp(-2 pi j k / N)); every other even size: the direct
+    // sums above (twiddle = the N-entry table (cos, sin)(2 pi k / N))
+    const bool pow2 = windowSize >= 64 && (windowSize & (windowSize - 1)) == 0;
+    const int logN = pow2 ? ilog2_exact(windowSize) : 0;
     if (!in_ring || !out_ring || !X || !Y || !C || !HMask || !tfMask || !hist || !hist_pos || !target || !W || !cosT || !sinT ||
         !window || !synthesis_window || !twiddle || (!frames_mode && (!block_in || !block_out)))
         return GCCNMF_ERR_ARG;
     if (numHUpdates < 0 || (numHUpdates > 0 && (!colsumW || !Hcoef || !Rv)) || out_delay_blocks < 1 || out_delay_blocks > 7) return GCCNMF_ERR_ARG;
-    if (logN < 6 || logN > 12 || hopSize < 1 || blockSize < hopSize || blockSize % hopSize || K < 1 || Kp % 64 || Kp < K || D < 1 ||
+    if (windowSize < 4 || windowSize > 4096 || (windowSize & 1) || hopSize < 1 || blockSize < hopSize || blockSize % hopSize || K < 1 || Kp % 64 || Kp < K || D < 1 ||
         D > 1024 || Dp % 32 || Dp < D || numTDOAHistory < 1 || localization_window < 1 || localization_window > numTDOAHistory)
         return GCCNMF_ERR_ARG;
     const int Tc = blockSize / hopSize, F = windowSize / 2 + 1;
     const int ring = frames_mode ? Tc * windowSize : 8 * blockSize;
-    if (!frames_mode && (ring < windowSize + (Tc - 1) * hopSize || 2 * ring > 8 * 1024)) return GCCNMF_ERR_UNSUPPORTED;
+    if (!frames_mode && ring < windowSize + (Tc - 1) * hopSize) return GCCNMF_ERR_UNSUPPORTED;      // the 8-block buffer must hold one block's windows
     const int start0 = frames_mode ? 0 : ring - windowSize - (Tc - 1) * hopSize;
     const int start_step = frames_mode ? windowSize : hopSize;
     hipStream_t s = (hipStream_t)stream;
@@ -495,8 +614,14 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
         hipLaunchKernelGGL(rt_shift_kernel, dim3(1), dim3(1024), 0, s, in_ring, out_ring, block_in, blockSize, ring);
         GCCNMF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(rt_frames_kernel, dim3(Tc), dim3(FFT_NT), lds, s, in_ring, ring, windowSize, logN, start0, start_step, Tc,
-                       window, (const float2*)twiddle, (float2*)X, (float2*)C);
+    const size_t lds_dft = sizeof(float2) * (2 * windowSize + 2);
+    if (pow2) {
+        hipLaunchKernelGGL(rt_frames_kernel, dim3(Tc), dim3(FFT_NT), lds, s, in_ring, ring, windowSize, logN, start0, start_step, Tc,
+                           window, (const float2*)twiddle, (float2*)X, (float2*)C);
+    } else {
+        hipLaunchKernelGGL(rt_frames_dft_kernel, dim3(gccnmf_ceil_div(F, 64), Tc), dim3(256), lds_dft, s, in_ring, ring, windowSize, start0,
+                           start_step, Tc, window, (const float2*)twiddle, (float2*)X, (float2*)C);
+    }
     GCCNMF_CHECK_LAUNCH();
     if (separation_enabled) {
         hipLaunchKernelGGL(rt_gccnmf_kernel, dim3(Kp / 32, Tc), dim3(64 * RT_G_WAVES), 0, s, (const float2*)C, cosT, sinT, W, F, K, Kp, D, Dp, Tc,
@@ -519,9 +644,18 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
             GCCNMF_CHECK_LAUNCH();
         }
     }
-    hipLaunchKernelGGL(rt_synth_kernel, dim3(1), dim3(FFT_NT), lds, s, (const float2*)(separation_enabled ? Y : X), windowSize, logN,
-                       start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, out_delay_blocks, synthesis_window, (const float2*)twiddle,
-                       out_ring, block_out);
+    if (pow2) {
+        hipLaunchKernelGGL(rt_synth_kernel, dim3(1), dim3(FFT_NT), lds, s, (const float2*)(separation_enabled ? Y : X), windowSize, logN,
+                           start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize, out_delay_blocks, synthesis_window,
+                           (const float2*)twiddle, out_ring, block_out);
+    } else {
+        // positions that receive a frame this call, plus the block handed out (it may lie in front of them)
+        const int h0 = ring - (out_delay_blocks + 1) * blockSize;
+        const int s_lo = frames_mode ? 0 : (start0 < h0 ? start0 : (h0 > 0 ? h0 : 0));
+        hipLaunchKernelGGL(rt_synth_dft_kernel, dim3(gccnmf_ceil_div(ring - s_lo, 256)), dim3(256), lds_dft, s,
+                           (const float2*)(separation_enabled ? Y : X), windowSize, start0, start_step, frames_mode ? 0 : 1, Tc, ring, blockSize,
+                           out_delay_blocks, s_lo, synthesis_window, (const float2*)twiddle, out_ring, block_out);
+    }
     GCCNMF_CHECK_LAUNCH();
     if (skip_localize) return GCCNMF_OK;
     hipLaunchKernelGGL(rt_localize_kernel, dim3(1), dim3(1024), 0, s, (const float2*)C, cosT, sinT, F, D, Dp, Dq, Tc, hist,

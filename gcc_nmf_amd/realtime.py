@@ -50,8 +50,10 @@ class GCCNMFProcessor(object):
                  microphoneSeparationInMetres, localizationEnabled, localizationWindowSize, gccPHATHistory=None, tdoaHistory=None,
                  inputSpectrogramHistory=None, outputSpectrogramHistory=None, coefficientMaskHistories=None, numTDOAs=64,
                  numTDOAHistory=128, analysisWindow=None, synthesisWindow=None):
-        if int(windowSize) not in (64, 128, 256, 512, 1024, 2048, 4096):
-            raise ValueError('windowSize=%r is not supported by the HIP frame processor: a power of two from 64 to 4096' % (windowSize,))
+        # any even size like the reference (numpy.fft.rfft / irfft, gccNMFProcessor.py:202,:231): powers of two from 64 up take the
+        # radix-2 LDS transform, every other even size the direct-sum kernels of csrc/rt.hip
+        if int(windowSize) != windowSize or int(windowSize) < 4 or int(windowSize) > 4096 or int(windowSize) % 2:
+            raise ValueError('windowSize=%r is not supported by the HIP frame processor: an even size from 4 to 4096' % (windowSize,))
         self.lib = _hip.lib()
         self.device = _device()
         self.sampleRate, self.windowSize, self.numTimePerChunk = sampleRate, int(windowSize), int(numTimePerChunk)
@@ -106,7 +108,12 @@ class GCCNMFProcessor(object):
         self.dSynthWindow = torch.from_numpy(np.ascontiguousarray(self.synthesisWindowFunction[:, 0])).to(dev)
         self.dColsum = padded(self.W.sum(axis=0, dtype=np.float32), (self.Kp,), dev)          # sum_f W: denominator of the H update
         self.dHcoef, self.dRv = z(self.Kp, Tc, 2), z(F, Tc, 2)
-        self.dTwiddle = torch.from_numpy(fft_twiddles(self.windowSize)).to(dev)
+        N = self.windowSize
+        if N >= 64 and N & (N - 1) == 0:
+            self.dTwiddle = torch.from_numpy(fft_twiddles(N)).to(dev)
+        else:           # the full-circle table of the direct-sum kernels: (cos, sin)(2 pi k / N), float64 on the host like the twiddles
+            ang = 2.0 * np.pi * np.arange(N, dtype=np.float64) / N
+            self.dTwiddle = torch.from_numpy(np.ascontiguousarray(np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)).reshape(-1)).to(dev)
         # what the host mirrors are computed from lives in ONE block, so that they cost one download per call: X | Y | HMask | gccPHAT | target
         sizes = [2 * F * Tc * 2, 2 * F * Tc * 2, self.Kp * Tc, D * Tc, 4]
         offs = np.concatenate([[0], np.cumsum([-(-n // 4) * 4 for n in sizes])])
@@ -239,9 +246,8 @@ class StreamingGCCNMF(object):
                                  % (self.outputDelayBlocks, support, self.outputDelayBlocks * int(blockSize) + int(hopSize)))
         if blockSize % hopSize or blockSize // hopSize != processor.numTimePerChunk:
             raise ValueError('blockSize/hopSize must equal the processor\'s numTimePerChunk')
-        if blockSize > 512 or 8 * blockSize < processor.windowSize + (processor.numTimePerChunk - 1) * hopSize:
-            raise ValueError('blockSize=%d is not supported: the 8-block device rings (utils.py:87-92) hold at most 512 samples per '
-                             'block and must cover one window' % blockSize)
+        if 8 * blockSize < processor.windowSize + (processor.numTimePerChunk - 1) * hopSize:
+            raise ValueError('blockSize=%d is not supported: the 8-block buffers (utils.py:87-92) must cover one block\'s windows' % blockSize)
         self.p, self.hopSize, self.blockSize = processor, int(hopSize), int(blockSize)
         dev = processor.device
         self.in_ring = torch.zeros((2, 8 * blockSize), dtype=torch.float32, device=dev)

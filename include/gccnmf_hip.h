@@ -260,8 +260,11 @@ int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int
  * windows.  Replaces GCCNMFProcessor.processFrames (gccNMF/realtime/gccNMFProcessor.py:201-270, a Theano graph in the
  * reference) together with OverlapAddProcessor.processFrames (gccNMF/realtime/utils.py:99-116) and the gccPHAT history /
  * online localisation (:214-222, utils.py:34-70).  Six launches on `stream`, no host synchronisation.
- * LIMITS: windowSize a power of two in [64, 4096]; streaming mode needs blockSize <= 512 (the two 8-block rings are shifted
- * by one 1024-thread workgroup holding 8 samples per thread) and 8*blockSize >= one window -> GCCNMF_ERR_UNSUPPORTED.
+ * Sizes: ANY even windowSize in [4, 4096] and any blockSize, like the reference (numpy.fft.rfft / irfft of any length,
+ * gccNMFProcessor.py:202,:231; buffers of any size, realtime/utils.py:72-97).  Powers of two from 64 up run the radix-2 LDS transform
+ * (`twiddle` = windowSize/2 complex values exp(-2j pi k / N), as for gccnmf_stft_stereo); every other even size is evaluated as the
+ * direct sum against `twiddle` = the windowSize-entry table (cos, sin)(2 pi k / N) (csrc/rt.hip: rt_frames_dft / rt_synth_dft).
+ * The only requirement left: 8*blockSize >= one block's windows (the reference's 8-block buffers) -> else GCCNMF_ERR_UNSUPPORTED.
  *   block_in / block_out [2][blockSize]            new samples in, the block two blocks old out (utils.py:116)
  *   in_ring / out_ring   [2][8*blockSize]          state: the reference's 8-block buffers
  *   X, Y [2][F][Tc] complex, C [F][Tc] complex     rfft (not conjugated), masked spectrogram, PHAT coherence

@@ -41,6 +41,8 @@ FRAME_CASES = {   # name: (windowSize, K, D, Tc, d, seed)
     'b': (512, 200, 40, 4, 0.1, 1),
     'c': (1024, 1024, 64, 2, 0.1, 2),
     'd': (256, 96, 33, 8, 0.25, 3),
+    'e': (400, 64, 48, 2, 0.1, 4),            # round 4: window sizes off the powers of two (the reference takes any, :202,:231)
+    'f': (1000, 128, 64, 1, 0.1, 5),
 }
 TARGETS = [(TARGET_MODE_WINDOW_FUNCTION, (9.6, 5.0, 2.0, 0.0)), (TARGET_MODE_WINDOW_FUNCTION, (20.0, 3.0, 1.0, 0.2)),
            (TARGET_MODE_BOXCAR, (20.0, 12.0, 1.0, 0.0))]
@@ -48,6 +50,9 @@ STREAM_CASES = {  # name: (windowSize, hop, block, K, D, d, numBlocks, signal, l
     'default': (1024, 512, 512, 64, 64, 0.1, 60, 'synthetic', 6),             # realtime/config.py:50-73 defaults
     'lowlatency': (512, 64, 64, 256, 64, 0.1, 300, 'synthetic', 6),           # BASELINE config 5's window / hop
     'dev1': (512, 128, 256, 128, 48, 1.0, 80, 'dev1', 4),                      # two windows per block, a reference wav
+    'ws400': (400, 100, 200, 64, 48, 0.1, 80, 'synthetic', 6),                 # round 4: non-power-of-two window, two windows per block
+    'ws1000': (1000, 500, 500, 96, 64, 0.1, 40, 'synthetic', 6),
+    'bigblock': (1024, 512, 1024, 64, 64, 0.1, 30, 'synthetic', 6),            # blocks of more than 512 samples
 }
 
 
@@ -116,13 +121,20 @@ def main():
                 'theano': 'oracle/theano_stub (NumPy-evaluated stand-in), reference classes imported unmodified', 'files': []}
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')                                          # nanmean of all-NaN start-up columns
+        only = set(sys.argv[1:])                   # names to (re)write; nothing given = everything.  The manifest always lists every case.
         for name, c in FRAME_CASES.items():
             path = os.path.join(OUT, 'rt_frames_%s.npz' % name)
+            if only and name not in only and os.path.exists(path):
+                manifest['files'].append(os.path.basename(path))
+                continue
             np.savez_compressed(path, **frames_case(name, *c))
             manifest['files'].append(os.path.basename(path))
             print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.0))
         for name, c in STREAM_CASES.items():
             path = os.path.join(OUT, 'rt_stream_%s.npz' % name)
+            if only and name not in only and os.path.exists(path):
+                manifest['files'].append(os.path.basename(path))
+                continue
             r = stream_case(name, *c)
             np.savez_compressed(path, **r)
             manifest['files'].append(os.path.basename(path))

@@ -100,7 +100,7 @@ GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 NEAR_TIE = 1e-4        # relative top-2 gap of the reference's float32 scores below which an arg-max may legitimately differ
 
 
-@pytest.mark.parametrize('case', ['a', 'b', 'c', 'd'])
+@pytest.mark.parametrize('case', ['a', 'b', 'c', 'd', 'e', 'f'])        # e, f: windowSize 400 / 1000 -> the direct-sum kernels
 def test_process_frames_vs_reference_goldens(case):
     from gcc_nmf_amd.realtime import GCCNMFProcessor
     g = np.load(os.path.join(GOLD, 'rt_frames_%s.npz' % case))
@@ -126,7 +126,7 @@ def test_process_frames_vs_reference_goldens(case):
             assert np.abs(out - y).max() < 1e-5 * np.abs(y).max() + 1e-7
 
 
-@pytest.mark.parametrize('case', ['default', 'lowlatency', 'dev1'])
+@pytest.mark.parametrize('case', ['default', 'lowlatency', 'dev1', 'ws400', 'ws1000', 'bigblock'])
 def test_stream_vs_reference_goldens(case):
     """The fused block call against a block-by-block run of the reference's OverlapAddProcessor + GCCNMFProcessor with online
     localisation: same tracked TDOA after every block, same audio."""
@@ -155,7 +155,7 @@ def test_stream_vs_reference_goldens(case):
     assert np.sqrt(sq / (2 * B * compared)) < 3e-5 * np.abs(x).max(), np.sqrt(sq / (2 * B * compared))
 
 
-@pytest.mark.parametrize('case', ['default', 'lowlatency', 'dev1'])
+@pytest.mark.parametrize('case', ['default', 'lowlatency', 'dev1', 'ws400', 'bigblock'])
 def test_history_mirrors_vs_reference_stream_goldens(case):
     """the host mirrors the reference GUI reads (gccNMFProcessor.py:211-229).  gccPHATHistory / tdoaHistory objects passed
     to the constructor are filled after every block; after the whole stream they hold what the reference's own

@@ -230,3 +230,24 @@ def test_frame_is_the_reference_strided_view():
     want = w * np.fft.ifft(full).real
     got = X.real @ ib[:6, :n_fft].astype(np.float64) + X.imag @ ib[Fp:Fp + 6, :n_fft].astype(np.float64)
     assert np.allclose(got, want, atol=1e-6)
+
+
+def test_lds_dma_statements_set_m0_themselves():
+    """M0 (the LDS-DMA destination base) is a compiler-reserved register that cannot be declared as an inline-asm clobber (hipcc only
+    warns).  The rule that makes that safe -- every asm statement that issues an LDS-DMA load writes M0 itself, in front of the load, and
+    no other statement reads M0 -- is checked on the sources, so a later edit cannot silently break it (fragility)."""
+    csrc = os.path.join(REPO, 'gcc_nmf_amd', 'csrc')
+    dma = 0
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith(('.h', '.hip')):
+            continue
+        src = open(os.path.join(csrc, name)).read()
+        for m in re.finditer(r'asm\s+volatile\s*\((.*?)\)\s*;', src, flags=re.S):
+            text = m.group(1)
+            strings = ''.join(re.findall(r'"((?:[^"\\]|\\.)*)"', text.split(':')[0]))
+            if re.search(r'global_load_lds|buffer_load\w*[^"]*\blds\b', strings):
+                dma += 1
+                assert 's_mov_b32 m0' in strings and strings.index('s_mov_b32 m0') < re.search(r'global_load_lds|buffer_load', strings).start(), (name, strings)
+            elif re.search(r'\bm0\b', strings):
+                raise AssertionError('%s: an asm statement touches m0 without being an LDS-DMA load: %s' % (name, strings))
+    assert dma >= 2
