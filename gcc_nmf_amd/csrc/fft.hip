@@ -24,9 +24,9 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
                                                              int logN, int hop, int T, const float* __restrict__ window,
                                                              const float2* __restrict__ twiddle, float2* __restrict__ X,
                                                              float* __restrict__ V, float* __restrict__ CC, int F, int Fp,
-                                                             int Np, int Tp) {
+                                                             int Np, int Tp, int ps) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
-    const int zstride = N + FFT_ZPAD;
+    const int zstride = N + (N >> ps) + FFT_ZPAD;
     float2* z = fft_smem;
     float2* tw = fft_smem + TB * zstride;
     const int groups = (T + TB - 1) / TB;
@@ -50,11 +50,11 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
                 v = make_float2(w * xl[s], w * xr[s]);
             }
         }
-        z[tb * zstride + bitrev(n, logN)] = v;
+        z[tb * zstride + fft_pad(bitrev(n, logN), ps)] = v;
     }
     __syncthreads();
 #if !(FFT_ABL & 1)
-    fft_stages<false, TB>(z, tw, N, logN, zstride);
+    fft_stages_any<false, TB>(z, tw, N, logN, zstride, ps);
 #endif
 #if FFT_ABL & 2
     if (z[threadIdx.x].x != 123.456f) return;       // timing experiment: no output stage
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
         const int f = idx / TB, tb = idx - f * TB;
         const int t = t0 + tb;
         if (t >= T) continue;
-        const float2 zk = z[tb * zstride + f];
-        const float2 zn = z[tb * zstride + ((N - f) & (N - 1))];
+        const float2 zk = z[tb * zstride + fft_pad(f, ps)];
+        const float2 zn = z[tb * zstride + fft_pad((N - f) & (N - 1), ps)];
         // reference stores the CONJUGATE of the FFT (librosaSTFT.py:176-179)
         const float2 XL = make_float2(0.5f * (zk.x + zn.x), -0.5f * (zk.y - zn.y));
         const float2 XR = make_float2(0.5f * (zk.y + zn.y), 0.5f * (zk.x - zn.x));
@@ -101,9 +101,9 @@ template <int TB>
 __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int T,
                                                               const float* __restrict__ window,
                                                               const float2* __restrict__ twiddle, float* __restrict__ frames,
-                                                              int F, int Fp, int Tp) {
+                                                              int F, int Fp, int Tp, int ps) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
-    const int zstride = N + FFT_ZPAD;
+    const int zstride = N + (N >> ps) + FFT_ZPAD;
     float2* z = fft_smem;
     float2* tw = fft_smem + TB * zstride;
     const int groups = (T + TB - 1) / TB;
@@ -132,11 +132,11 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
             fb.y = 0.f;
         }
         float2* zz = z + tb * zstride;
-        zz[bitrev(f, logN)] = make_float2(fa.x - fb.y, fa.y + fb.x);
-        if (f != 0 && f != N / 2) zz[bitrev(N - f, logN)] = make_float2(fa.x + fb.y, fb.x - fa.y);
+        zz[fft_pad(bitrev(f, logN), ps)] = make_float2(fa.x - fb.y, fa.y + fb.x);
+        if (f != 0 && f != N / 2) zz[fft_pad(bitrev(N - f, logN), ps)] = make_float2(fa.x + fb.y, fb.x - fa.y);
     }
     __syncthreads();
-    fft_stages<true, TB>(z, tw, N, logN, zstride);
+    fft_stages_any<true, TB>(z, tw, N, logN, zstride, ps);
 
     const float invN = 1.0f / (float)N;
     float* Fa = frames + (((long)b * nsig + 2 * pr) * T) * N;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
         const int tb = idx / N, n = idx - tb * N;
         const int t = t0 + tb;
         if (t >= T) continue;
-        const float2 v = z[tb * zstride + n];
+        const float2 v = z[tb * zstride + fft_pad(n, ps)];
         const float w = window[n];
         Fa[(long)t * N + n] = w * (v.x * invN);
         Fb[(long)t * N + n] = w * (v.y * invN);
@@ -191,10 +191,10 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 #endif
 __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int hop, int T,
                                                              const float* __restrict__ window, const float2* __restrict__ twiddle,
-                                                             int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y) {
+                                                             int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y, int ps) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
     constexpr int TB = ISTFT_TB, G = ISTFT_TB * ISTFT_SUB;
-    const int zstride = N + FFT_ZPAD;
+    const int zstride = N + (N >> ps) + FFT_ZPAD;
     float2* z = fft_smem;
     float2* tw = fft_smem + TB * zstride;
     const int span = N + hop * (TB - 1);                  // samples one sub-batch touches
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
                 fb.y = 0.f;
             }
             float2* zz = z + tb * zstride;
-            zz[bitrev(f, logN)] = make_float2(fa.x - fb.y, fa.y + fb.x);
-            if (f != 0 && f != N / 2) zz[bitrev(N - f, logN)] = make_float2(fa.x + fb.y, fb.x - fa.y);
+            zz[fft_pad(bitrev(f, logN), ps)] = make_float2(fa.x - fb.y, fa.y + fb.x);
+            if (f != 0 && f != N / 2) zz[fft_pad(bitrev(N - f, logN), ps)] = make_float2(fa.x + fb.y, fb.x - fa.y);
         }
         __syncthreads();
-        fft_stages<true, TB>(z, tw, N, logN, zstride);
+        fft_stages_any<true, TB>(z, tw, N, logN, zstride, ps);
         // every thread owns the accumulator positions i = tid, tid + NT, ...: frames added in ascending order, no hazards
         for (int i = threadIdx.x; i < span; i += FFT_NT) {
             float va = acc_a[i], vb = acc_b[i];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
             for (int tb = 0; tb < TB; ++tb) {
                 const int n = i - tb * hop;
                 if (n >= 0 && n < N && fs + tb < t_end) {
-                    const float2 v = z[tb * zstride + n];
+                    const float2 v = z[tb * zstride + fft_pad(n, ps)];
                     const float w = window[n];
                     // (no fma across the window product: this file is compiled with -ffp-contract=off; the reference adds whole frames)
                     va = va + w * (v.x * invN);
@@ -333,6 +333,10 @@ __global__ __launch_bounds__(256) void pcm_pack_kernel(const float* __restrict__
     pcm[g * L + m] = make_short2((short)(int)a, (short)(int)b);
 }
 
+extern int gccnmf_tune_fft_r16;     // key 15 (nmf.hip): 1 (default) = up to four butterfly stages per LDS round trip, 0 = one (same bits)
+static inline int fft_ps() { return gccnmf_tune_fft_r16 ? 4 : FFT_NOPAD; }
+static inline size_t fft_rows_bytes(int tb, int n_fft, int ps) { return sizeof(float2) * ((size_t)tb * fft_row_floats2(n_fft, ps) + n_fft / 2); }
+
 extern "C" {
 
 static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch, const float* window,
@@ -343,9 +347,10 @@ static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, i
     const int F = n_fft / 2 + 1;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     // eight frames per workgroup; four when eight no longer fit the 160 KB of LDS (n_fft = 4096)
-    const bool small_tb = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) > 160 * 1024;
+    const int ps = fft_ps();
+    const bool small_tb = fft_rows_bytes(FFT_TB, n_fft, ps) > 160 * 1024;
     const int tb = small_tb ? FFT_TB / 2 : FFT_TB;
-    const size_t lds = sizeof(float2) * ((size_t)tb * (n_fft + FFT_ZPAD) + n_fft / 2);
+    const size_t lds = fft_rows_bytes(tb, n_fft, ps);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
     const void* fn = pcm16 ? (small_tb ? (const void*)stft_stereo_kernel<true, FFT_TB / 2> : (const void*)stft_stereo_kernel<true, FFT_TB>)
                            : (small_tb ? (const void*)stft_stereo_kernel<false, FFT_TB / 2> : (const void*)stft_stereo_kernel<false, FFT_TB>);
@@ -355,7 +360,7 @@ static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, i
     const int groups = gccnmf_ceil_div(T, tb);
 #define GCCNMF_LAUNCH_STFT(P_, TB_)                                                                                                       \
     hipLaunchKernelGGL((stft_stereo_kernel<P_, TB_>), dim3(batch * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float*)x, x_stride, \
-                       n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp)
+                       n_samples, n_fft, logN, hop, T, window, (const float2*)twiddle, (float2*)X, V, CC, F, p.Fp, p.Np, p.Tp, ps)
     if (pcm16) {
         if (small_tb) GCCNMF_LAUNCH_STFT(true, FFT_TB / 2);
         else GCCNMF_LAUNCH_STFT(true, FFT_TB);
@@ -384,6 +389,7 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
     if (!spec || !window || !twiddle || !y || logN < 6 || logN > 12 || hop < 1 || T < 1 || batch < 1 || nsig < 2 || (nsig & 1))
         return GCCNMF_ERR_ARG;
     const int F = n_fft / 2 + 1;
+    const int ps = fft_ps();
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     if (!frames) {      // fused form: no frame buffer, one pass
         const int trim = center ? n_fft / 2 : 0;
@@ -391,20 +397,20 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
         if (L < 1) return GCCNMF_ERR_ARG;
         const int span = n_fft + hop * (ISTFT_TB - 1);
         if (span > 8 * FFT_NT) return GCCNMF_ERR_UNSUPPORTED;          // hop > n_fft / 3 or so: use the two-kernel form
-        const size_t lds = sizeof(float2) * ((size_t)ISTFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) + sizeof(float) * 2 * span;
+        const size_t lds = fft_rows_bytes(ISTFT_TB, n_fft, ps) + sizeof(float) * 2 * span;
         if (lds > 64 * 1024) {
             if (hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return GCCNMF_ERR_LAUNCH;
         }
         const int groups = gccnmf_ceil_div(T, ISTFT_TB * ISTFT_SUB);
         hipLaunchKernelGGL(istft_fused_kernel, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float2*)spec,
-                           nsig, n_fft, logN, hop, T, window, (const float2*)twiddle, F, p.Fp, p.Tp, trim, L, gain, y);
+                           nsig, n_fft, logN, hop, T, window, (const float2*)twiddle, F, p.Fp, p.Tp, trim, L, gain, y, ps);
         GCCNMF_CHECK_LAUNCH();
         return GCCNMF_OK;
     }
-    const bool small_tb = sizeof(float2) * ((size_t)FFT_TB * (n_fft + FFT_ZPAD) + n_fft / 2) > 160 * 1024;
+    const bool small_tb = fft_rows_bytes(FFT_TB, n_fft, ps) > 160 * 1024;
     const int tb = small_tb ? FFT_TB / 2 : FFT_TB;
-    const size_t lds = sizeof(float2) * ((size_t)tb * (n_fft + FFT_ZPAD) + n_fft / 2);
+    const size_t lds = fft_rows_bytes(tb, n_fft, ps);
     if (lds > 160 * 1024) return GCCNMF_ERR_UNSUPPORTED;
     if (lds > 64 * 1024) {
         const void* fn = small_tb ? (const void*)istft_frames_kernel<FFT_TB / 2> : (const void*)istft_frames_kernel<FFT_TB>;
@@ -414,10 +420,10 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
     hipStream_t s = (hipStream_t)stream;
     if (small_tb)
         hipLaunchKernelGGL(istft_frames_kernel<FFT_TB / 2>, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, s, (const float2*)spec, nsig,
-                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp);
+                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp, ps);
     else
         hipLaunchKernelGGL(istft_frames_kernel<FFT_TB>, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, s, (const float2*)spec, nsig,
-                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp);
+                           n_fft, logN, T, window, (const float2*)twiddle, frames, F, p.Fp, p.Tp, ps);
     GCCNMF_CHECK_LAUNCH();
     const int trim = center ? n_fft / 2 : 0;
     const int L = n_fft + hop * (T - 1) - 2 * trim;

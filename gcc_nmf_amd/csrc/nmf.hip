@@ -30,6 +30,7 @@ int gccnmf_tune_direct = 1;        // key 10: 1 (default) = launches that cannot
 int gccnmf_tune_direct_tile = 0;   // key 11: 0 = tile by the cost model, 1..8 = that tile for every direct launch (experiments)
 int gccnmf_tune_direct_batch = 4;  // key 12: largest batch that takes the direct path (measured, K = 1024: 4 files 21.8 ms against 25.8 on the ring
                                    // kernel, 8 files 41.5 / 41.3, 12 files 61.9 / 59.3)
+int gccnmf_tune_fft_r16 = 1;       // key 15: 1 (default) = the offline STFT / iSTFT run up to four radix-2 stages per LDS round trip (fft_core.h)
 int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
 int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
 long long* gccnmf_trace_buf = nullptr;
@@ -73,6 +74,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 11 && value >= 0 && value <= 8) {
         gccnmf_tune_direct_tile = value;
+        return GCCNMF_OK;
+    }
+    if (key == 15 && (value == 0 || value == 1)) {
+        gccnmf_tune_fft_r16 = value;
         return GCCNMF_OK;
     }
     if (key == 14 && (value == 0 || value == 1)) {

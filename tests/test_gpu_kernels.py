@@ -228,6 +228,41 @@ def test_stft_stereo(hip, n_fft, hop, n):
     assert np.abs(X - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('n_fft,hop,n', [(64, 16, 2000), (128, 32, 3000), (256, 100, 3000), (512, 128, 9000), (1024, 256, 40000), (2048, 512, 30000),
+                                         (4096, 1024, 40000)])
+def test_register_pass_fft_is_bitwise_the_stage_per_round_trip_fft(hip, n_fft, hop, n):
+    """Round 4 runs up to four radix-2 stages per LDS round trip (fft_core.h: fft_pass); every butterfly computes the same expression on
+    the same operands, so the STFT (X, V, coherence) and both inverse forms give the SAME BITS as the one-stage-per-round-trip routine
+    (tuning key 15 = 0), at every supported size."""
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    lib = hip.lib()
+    xs = synthetic_batch(3, 2, numSamples=n)
+    outs = []
+    for r16 in (0, 1):
+        assert lib.gccnmf_set_tuning(15, r16) == 0
+        e = GCCNMFEngine(n, windowSize=n_fft, hopSize=hop, dictionarySize=16, numIterations=2, batch=2, numTargets=2)
+        e.upload(xs)
+        e.stft()
+        X, V, C = e.X.clone(), e.V.clone(), e.CC.clone()
+        # the inverse transform of the mixture spectrogram itself (spec = X for both 'targets'), fused and two-kernel forms
+        e.spec.copy_(torch.stack([e.X[:, 0], e.X[:, 1], e.X[:, 1], e.X[:, 0]], dim=1))
+        ys = []
+        for fused in ([True, False] if e.fused_istft or n_fft + 3 * hop <= 2048 else [False]):
+            e.fused_istft = fused
+            e.istft()
+            ys.append(e.y.clone())
+        outs.append((X, V, C, ys))
+    lib.gccnmf_set_tuning(15, 1)
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert len(outs[0][3]) == len(outs[1][3])
+    for a, b in zip(outs[0][3], outs[1][3]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    if len(outs[1][3]) == 2:
+        assert torch.equal(outs[1][3][0], outs[1][3][1])          # fused == two-kernel form, as before
+
+
 def test_istft_n_fft_4096(hip):
     from gcc_nmf_amd.librosaSTFT import stft, istft
     rng = np.random.RandomState(7)
