@@ -37,7 +37,7 @@ long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
 extern "C" {
-int gccnmf_version(void) { return 103; }   // round 3: shared run + RCCL hook, any-n_fft DFT path, tile-layout cost model
+int gccnmf_version(void) { return 104; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT
 
 int gccnmf_set_tuning(int key, int value) {
     if (key == 1) {
