@@ -22,6 +22,7 @@
 
 #define DIRECT_MAX_DEVICES 64
 extern int gccnmf_tune_ablate;
+extern int gccnmf_tune_direct_depth;
 
 typedef float df32x4 __attribute__((ext_vector_type(4)));
 typedef float df32x2 __attribute__((ext_vector_type(2)));
@@ -459,6 +460,130 @@ int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream) {
 extern "C" int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream) {
     if (!desc || tile < 0) return GCCNMF_ERR_ARG;
     return gccnmf_direct_launch(*desc, epilogue, tile, (hipStream_t)stream);
+}
+
+// ---- experiment: the THROUGHPUT tile without LDS (round 4) ------------------------------------------------------------------
+// The same idea at batch scale, for GEMMs whose operands are both reduction-major already (the H update: A = W [f][k], B = R [f][n]):
+// a 512 x 64 workgroup tile as in gemm_dma.h (4 waves x 128 x 64, v_mfma_f32_32x32x2_f32), but every wave fetches its own 128 rows
+// of A (one 16-byte load per lane and k-step pair = four interleaved 32-row blocks) and the tile's 64 columns of B straight from
+// L1 / L2 into registers: no LDS-DMA, no fragment reads, no barrier -- the four waves never synchronise.  B is fetched by all four
+// waves of a workgroup (the second to fourth hit the CU's vector L1).  Reached through gccnmf_debug_gemm (layout bit 32) for timing.
+#include "gemm_mfma.h"
+template <int NBUF>
+__global__ __launch_bounds__(256, 2) void gccnmf_gemm_stream_kernel(const GemmArgs p) {
+    constexpr int BM = 512, BN = 64, RW = 128, CK = 8;         // chunk = 8 reduction rows = 4 MFMA steps of 2
+    const int tiles = p.tiles_m * p.tiles_n;
+    int file = blockIdx.x / tiles, tile = blockIdx.x - file * tiles;
+    if (p.xcd_affine) {      // XCD x owns a contiguous eighth of the file-major tile list (blocks b, b + 8, ... run on XCD b % 8)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, idx = xcd * p.xcd_affine + slot;
+        if (idx >= p.batch * tiles) return;
+        file = idx / tiles;
+        tile = idx - file * tiles;
+    }
+    file = __builtin_amdgcn_readfirstlane(file);
+    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = __builtin_amdgcn_readfirstlane(tile) - tm * p.tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_w = row0 + wave * RW;
+    if (row_w >= p.M) return;
+    const float* __restrict__ A = p.A + file * p.sA;
+    const float* __restrict__ B = p.B + file * p.sB;
+    const int nchunks = (p.Kd + CK - 1) / CK;
+    const unsigned chunkA = 4u * CK * (unsigned)p.lda, chunkB = 4u * CK * (unsigned)p.ldb;
+    const __amdgpu_buffer_rsrc_t rA = direct_rsrc(A, (unsigned)nchunks * chunkA), rB = direct_rsrc(B, (unsigned)nchunks * chunkB);
+    unsigned offA[4], offB0[4], offB1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        offA[s] = 4u * (unsigned)((2 * s + hh) * p.lda + min(row_w + 4 * l31, p.a_clamp));
+        offB0[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + l31, p.b_clamp + 3));
+        offB1[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + 32 + l31, p.b_clamp + 3));
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    struct Frag {
+        df32x4 a[4];
+        float b0[4], b1[4];
+    };
+    auto load = [&](Frag& f, int ch) {
+        const unsigned chu = (unsigned)__builtin_amdgcn_readfirstlane(min(ch, nchunks - 1));
+        const unsigned sa = chu * chunkA, sb = chu * chunkB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f.a[s] = DLoad<4>::ld(rA, offA[s], sa);
+            f.b0[s] = DLoad<1>::ld(rB, offB0[s], sb);
+            f.b1[s] = DLoad<1>::ld(rB, offB1[s], sb);
+        }
+    };
+    auto compute = [&](const Frag& f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][m], f.b0[s], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[s][m], f.b1[s], acc[m][1], 0, 0, 0);
+            }
+    };
+    auto interleave = [&]() {      // 12 loads dealt out over the chunk's 32 MFMAs
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    Frag f[NBUF];
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load(f[j], j);
+    int it = 0;
+    for (; it + NBUF <= nchunks; it += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            load(f[(j + NBUF - 1) % NBUF], it + j + NBUF - 1);
+            compute(f[j]);
+            interleave();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (it + j < nchunks) compute(f[j]);
+    // plain store: register r of block (m, n) is row row_w + 4 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + m, column col0 + 32 n + l31
+    float* C = p.C + file * p.sC;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_w + 4 * ((r & 3) + 8 * (r >> 2) + 4 * hh) + m;
+            if (row < p.M) {
+                if (col0 + l31 < p.N) C[(long)row * p.ldc + col0 + l31] = acc[m][0][r];
+                if (col0 + 32 + l31 < p.N) C[(long)row * p.ldc + col0 + 32 + l31] = acc[m][1][r];
+            }
+        }
+}
+
+int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream) {
+    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1 || (a.lda & 3)) return GCCNMF_ERR_ARG;
+    a.tiles_m = gccnmf_ceil_div(a.M, 512);
+    a.tiles_n = gccnmf_ceil_div(a.N, 64);
+    const int tiles = a.tiles_m * a.tiles_n;
+    int grid = a.batch * tiles;
+    if (a.xcd_affine && a.batch >= 8) {
+        a.xcd_affine = gccnmf_ceil_div(a.batch * tiles, 8);
+        grid = 8 * a.xcd_affine;
+    } else {
+        a.xcd_affine = 0;
+    }
+    if (gccnmf_tune_direct_depth == 2) hipLaunchKernelGGL(gccnmf_gemm_stream_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    else if (gccnmf_tune_direct_depth == 4) hipLaunchKernelGGL(gccnmf_gemm_stream_kernel<4>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gccnmf_gemm_stream_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
 }
 
 // ---- transposed copies ---------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 #include <mutex>
 #include "gemm_ring.h"
 #include "direct.h"
+int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);
 #include "../../include/gccnmf_hip.h"
 
 int gccnmf_tune_ablate = 0;
@@ -1144,6 +1145,7 @@ int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, in
     a.rowsumB = rowsumB; a.s_rowsumB = N;
     a.C = C; a.sC = sC; a.ldc = ldc;
     hipStream_t s = (hipStream_t)stream;
+    if (layout & 32) return (layout & 31) ? GCCNMF_ERR_ARG : gccnmf_launch_gemm_stream(a, s);      // experiment: the LDS-free throughput tile (direct.hip)
     const bool wide = layout & 8;
     if (!wide && gccnmf_tune_dma) {       // the throughput tile's default staging path (tuning key 3)
         switch (layout & 3) {

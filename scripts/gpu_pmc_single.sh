@@ -11,10 +11,10 @@ find $OUT/pmc_sq_single -name "*kernel_trace*" -delete
 python - "$OUT" <<'PY'
 import csv, collections, glob, json, os, sys
 out = sys.argv[1]
-files = glob.glob(os.path.join(out, 'pmc_sq_single', '*counter_collection.csv'))
+files = glob.glob(os.path.join(out, 'pmc_sq_single', '**', '*counter_collection.csv'), recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(files[0])):
-    if 'gccnmf_gemm_ring' in r['Kernel_Name'] or 'onepass' in r['Kernel_Name'] or 'div_partials' in r['Kernel_Name']:
+    if 'gccnmf_gemm_ring' in r['Kernel_Name'] or 'gccnmf_direct' in r['Kernel_Name'] or 'onepass' in r['Kernel_Name'] or 'div_partials' in r['Kernel_Name']:
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} | {'launches': len(next(iter(d.values())))} for k, d in agg.items()}
 json.dump(res, open(os.path.join(out, 'pmc_sq_single.json'), 'w'), indent=1)

@@ -62,6 +62,8 @@ def main():
         'K4b W update+normalise': lambda: stage(5),
         'K1 shape, store only (A_KC, tail)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Fp * g.Np),
         'K2 shape, store only (W^T.R)': lambda: dbg(W, R, G2, K, N, F, g.Kp, g.Np, g.Np, g.Kp - 4, g.Np - 4, 0, g.Fp * g.Kp, g.Fp * g.Np, g.Kp * g.Np),
+        'K2 shape, store only, LDS-free stream tile (direct.hip)': lambda: dbg(W, R, G2, K, N, F - 1, g.Kp, g.Np, g.Np, g.Kp - 4, g.Np - 4, 32, g.Fp * g.Kp, g.Fp * g.Np, g.Kp * g.Np),
+        'K2 shape, Kd=512, store only (dma tile)': lambda: dbg(W, R, G2, K, N, F - 1, g.Kp, g.Np, g.Np, g.Kp - 4, g.Np - 4, 0, g.Fp * g.Kp, g.Fp * g.Np, g.Kp * g.Np),
         'K4a shape, store only (KC,KC, tail)': lambda: dbg(R, H, U, F, K, N, g.Np, g.Np, g.Kp, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Kp),
         'K1 shape, store only, ONE H for all files (B L2-resident)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, 0, g.Fp * g.Np),
         'K1 shape, store only, ONE W,H, one output tile set': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, 0, 0, 0),

@@ -52,6 +52,7 @@ GEMM_CASES = [
     (3, 200, 64, 150, 1), (3 | 4, 513, 128, 300, 2), (3 | 4, 513, 200, 1244, 8), (3 | 8, 100, 256, 75, 1),
     (3 | 4 | 8, 129, 300, 50, 2),
     (16, 1024, 200, 513, 2), (16 | 8, 128, 300, 33, 9), (16, 300, 100, 17, 1),      # rank-1 reduction tail in the epilogue
+    (32, 1024, 1244, 512, 9), (32, 700, 130, 75, 2), (32, 100, 64, 16, 1),          # the LDS-free throughput tile (direct.hip, experiment)
 ]
 
 
@@ -89,7 +90,7 @@ def test_debug_gemm(hip, layout, M, N, Kd, batch):
     dC = torch.full((batch, M, ldc), -7.0, dtype=torch.float32, device='cuda')
     bscale = None
     dscale = None
-    if not b_kc and not (layout & 16):
+    if not b_kc and not (layout & 16) and not (layout & 32):
         bscale = (rng.rand(Kd16) + 0.5).astype(np.float32)
         dscale = dev(bscale)
     drow = torch.zeros((batch, N), dtype=torch.float32, device='cuda') if b_kc else None

@@ -96,6 +96,33 @@ def test_all_reference_mixtures_batched(K):
 
 
 @pytest.mark.parametrize('K', [128, 1024])
+def test_each_reference_mixture_alone_on_the_direct_path(K):
+    """Every reference mixture processed ALONE -- the call the reference driver and the notebooks make, which round 4 moved to the
+    direct-to-register kernels (csrc/direct.hip) -- against the reference's own outputs: TDOA indexes exact, masks exact outside the
+    reference's near-ties, waveforms, and at K = 1024 the factors themselves."""
+    names = ['dev1_female3_liverec_130ms_1m'] + WAVS
+    for i, w in enumerate(names):
+        x = golden_wav(w)[0]
+        e = engine(x.shape[1], dictionarySize=K, numIterations=100, batch=1)
+        y = e.separate(x)
+        g = golden('%s_hop256_K%d' % (w, K)) if i else golden('dev1_hop256_K%d' % K)
+        assert e.get_tdoa_indexes()[0].tolist() == list(g['idx']), w
+        flips, worst = mask_flips(e.get_argmax()[0], g)
+        assert worst < TIE_LIMIT, (w, flips, worst)
+        ref = g['y'][:, :, ::8] if 'y' in g.files else g['y_sub']
+        rms = np.sqrt(np.mean((y[0][:, :, ::8].astype(np.float64) - ref) ** 2))
+        assert rms < 1e-5, (w, rms)
+        wh = ''
+        if K == 1024:
+            gw = golden('wh_sub_K1024')
+            W, H = e.get_WH()
+            rw, rh = rel(W[0][:, ::16], gw[w + '_W']), rel(H[0][::16, ::2], gw[w + '_H'])
+            assert rw < 1e-4 and rh < 1e-4, (w, rw, rh)
+            wh = ' W rel %.2e H rel %.2e' % (rw, rh)
+        print('%s alone, K=%d: mask flips %d (largest reference gap %.1e) waveform rms %.2e%s' % (w, K, flips, worst, rms, wh))
+
+
+@pytest.mark.parametrize('K', [128, 1024])
 def test_hop128_reference_default(dev1, K):
     x, sr = dev1
     g = golden('dev1_female3_liverec_130ms_1m_hop128_K%d' % K)
