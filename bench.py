@@ -435,6 +435,8 @@ def main():
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t1) / 3
         out['single_file'] = {'frames_per_s': g.T / dt1, 'ms_per_file': 1e3 * dt1,
+                              # the whole path's algorithmic flop per frame over the time of ONE mixture alone (latency path, csrc/direct.hip)
+                              'frac_of_mfma_peak': flop_per_frame * g.T / dt1 / (F32_MFMA_PEAK_TFLOPS * 1e12),
                               # different GEMM tile (launch-size dependent) -> different summation grouping, not bitwise equal
                               'waveform_rms_vs_in_batch': float(np.sqrt(np.mean((e1.y[0].cpu().numpy().astype(np.float64) - e.y[0].cpu().numpy()) ** 2)))}
 
@@ -448,6 +450,29 @@ def main():
         out['dropin_performKLNMF'] = {'ms': 1e3 * (time.perf_counter() - t1), 'frames_per_s': g.T / (time.perf_counter() - t1),
                                       'what': 'gcc_nmf_amd.gccNMFFunctions.performKLNMF(V (%d, %d) ndarray, %d, %d, 0): host arrays in and out'
                                               % (g.F, g.N, K, iters)}
+
+    if rank == 0 and world == 1 and not a.skip_extras and (K, a.hop) != (128, 128):
+        # the reference driver's OWN call (gccNMF/runGCCNMF.py:41,60: dictionarySize = 128, hopSize = 128 -> performKLNMF(V (513, 2486), 128, 100, 0)),
+        # one mixture alone, next to the headline shape: what `python runGCCNMF.py` on top of dropin.install() spends on the device
+        e2 = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=128, numTDOAs=128, microphoneSeparationInMetres=1.0,
+                          numTargets=3, dictionarySize=128, numIterations=100, batch=1, device='cuda:%d' % local_rank)
+        e2.upload(xs[0])
+        e2.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            e2.run()
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t1) / 3
+        from gcc_nmf_amd import gccNMFFunctions as G
+        V2 = e2.get_V()[0]
+        G.performKLNMF(V2, 128, 2, 0)
+        t1 = time.perf_counter()
+        G.performKLNMF(V2, 128, 100, 0)
+        out['reference_driver_shape'] = {'what': 'one mixture at the reference driver\'s own parameters (runGCCNMF.py:41,60): K = 128, hop 128, 100 iterations',
+                                         'frames': e2.g.T, 'ms_per_file': 1e3 * dt2, 'frames_per_s': e2.g.T / dt2,
+                                         'dropin_performKLNMF_ms': 1e3 * (time.perf_counter() - t1)}
+        del e2
 
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and not a.skip_extras:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline

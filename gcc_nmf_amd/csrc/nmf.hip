@@ -830,6 +830,8 @@ struct SharedShard {
     float *H, *R, *Upart, *rowsum_part;
     float *parts, *rowsum_parts;      // one file in the plain layout: scratch of the latency path's split-K partials, else nullptr
     bool latency;                     // ... and the current tuning sends it down that path
+    bool direct;                      // ... on the direct-to-register kernels (round 4), else the round-3 split-K launches
+    DirectBufs d;                     // transposed copies (Wt, Ht, Rt) of such a shard, behind the split-K scratch
     NmfGeom g;
     int batch;
     long r_floats;
@@ -851,12 +853,13 @@ static bool shared_latency_shard(const NmfGeom& g, int batch, int ld) {         
     return shared_single_file_layout(g, batch, ld) && single_file_split(g, 1, g.Kp, gccnmf_tune_wh_splits) &&
            single_file_split(g, 1, g.Np, gccnmf_tune_rht_splits);
 }
-static long shared_split_floats(const NmfGeom& g) { return GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp); }
+static long shared_split_floats(const NmfGeom& g) { return GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp) + direct_floats(g, 1); }
 
 static SharedShard make_shard(const float* V, float* H, float* ws, int F, int N, int K, int batch, int ld) {
     SharedShard sh;
     sh.g = make_geom(F, N, K);
-    sh.latency = shared_latency_shard(sh.g, batch, ld);
+    sh.direct = shared_single_file_layout(sh.g, batch, ld) && direct_path(sh.g, 1);
+    sh.latency = sh.direct || shared_latency_shard(sh.g, batch, ld);
     if (ld > 0) {
         sh.g.ld = ld;
         sh.g.sV = sh.g.sH = N;              // the next file is the next column block
@@ -871,14 +874,18 @@ static SharedShard make_shard(const float* V, float* H, float* ws, int F, int N,
         sh.g = make_geom(F, N, K);              // (ld == Np: the plain single-file geometry; strides are irrelevant for one file)
         sh.parts = sh.rowsum_part + (long)batch * sh.g.Kp;
         sh.rowsum_parts = sh.parts + GCCNMF_SPLITS * (sh.g.sV > sh.g.sU ? sh.g.sV : sh.g.sU);
+        sh.d = direct_bufs(sh.g, sh.rowsum_parts + GCCNMF_SPLITS * (long)sh.g.Kp, 1);
     }
     return sh;
 }
 
 static int shared_begin(const SharedShard* sh, int n, const float* W, float* colsumW, float* hscale, int F, int K, hipStream_t s) {
     NmfGeom g = make_geom(F, 1, K);
-    for (int i = 0; i < n; ++i)      // R's padding (rows >= F, columns >= N) is a reduction operand of K2 and K4a: zero
+    for (int i = 0; i < n; ++i) {    // R's padding (rows >= F, columns >= N) is a reduction operand of K2 and K4a: zero
         if (hipMemsetAsync(sh[i].R, 0, sizeof(float) * sh[i].r_floats, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        // ... and so are the rows n >= N of Ht / Rt and the columns f >= F of Wt on the direct path
+        if (sh[i].parts && hipMemsetAsync(sh[i].d.Wt, 0, sizeof(float) * direct_floats(sh[i].g, 1), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(nmf_prepare_kernel, dim3(g.Kp / 16), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
@@ -931,6 +938,13 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
     // bit 1 = another unit's launches run beside these on a side stream: the tile-layout cost model of gemm_dma.h prices a launch that
     // has the chip to itself, so such units keep full tiles (their partial rounds overlap the neighbours' kernels)
     const int xcd = 1 | (beside_others ? 2 : 0);
+    if (sh.direct) {                            // one file alone: the direct-to-register kernels (csrc/direct.hip), W transposed per iteration
+        if ((rc = gccnmf_transpose_launch(W, 0, g.Kp, sh.d.Wt, sh.d.sWt, sh.d.ldwt, g.F, g.Kp, 1, s))) return rc;
+        if ((rc = direct_wh_div(g, sh.d, sh.V, W, sh.H, hscale, sh.R, false, 1, s))) return rc;
+        if ((rc = direct_update_h(g, sh.d, W, sh.R, sh.H, hscale, colsumW, alpha, eps, 1, s))) return rc;
+        if ((rc = direct_wh_div(g, sh.d, sh.V, W, sh.H, nullptr, sh.R, true, 1, s))) return rc;
+        return direct_rht(g, sh.d, sh.R, sh.Upart, sh.rowsum_part, 1, s);
+    }
     if (sh.latency) {                           // one file alone: the split-K launches of the latency path
         if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, hscale, sh.parts, sh.R, s))) return rc;
         if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, 1, 0, s))) return rc;
@@ -950,9 +964,10 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
 static int shared_reduce(const SharedShard& sh, float* partial, int accumulate, hipStream_t s) {
     const NmfGeom& g = sh.g;
     // (one file alone: the "files" are the parts of its split R.H^T reduction, added in ascending order)
-    const float* U = sh.latency ? sh.parts : sh.Upart;
-    const float* rowsum = sh.latency ? sh.rowsum_parts : sh.rowsum_part;
-    const int n = sh.latency ? gccnmf_tune_rht_splits : sh.batch;
+    const bool split = sh.latency && !sh.direct;
+    const float* U = split ? sh.parts : sh.Upart;
+    const float* rowsum = split ? sh.rowsum_parts : sh.rowsum_part;
+    const int n = split ? gccnmf_tune_rht_splits : sh.batch;
     hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3((unsigned)((g.sU + 255) / 256)), dim3(256), 0, s, U, g.sU, n, g.sU, partial, accumulate);
     GCCNMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nmf_reduce_files_kernel, dim3(gccnmf_ceil_div(g.Kp, 256)), dim3(256), 0, s, rowsum, (long)g.Kp, n, (long)g.Kp,
@@ -1019,7 +1034,7 @@ static int shared_finish(const SharedShard* sh, int n, float* hscale, int K, hip
 
 // the four-call protocol's workspace: one default-layout shard's scratch | colsumW [Kp] | hscale [Kp]
 static float* legacy_vec(const SharedShard& sh) {
-    return sh.parts ? sh.rowsum_parts + GCCNMF_SPLITS * (long)sh.g.Kp : sh.rowsum_part + (long)sh.batch * sh.g.Kp;
+    return sh.parts ? sh.rowsum_parts + GCCNMF_SPLITS * (long)sh.g.Kp + direct_floats(sh.g, 1) : sh.rowsum_part + (long)sh.batch * sh.g.Kp;
 }
 
 long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch) {

@@ -104,14 +104,20 @@ def performKLNMF(V, dictionarySize, numIterations, sparsityAlpha, epsilon=1e-16,
             b['init'][init_key] = init
     else:
         np.random.set_state(init['state'])
-    # the padding of the cached buffers is zero and stays zero (the kernels never write it): only the F x N / F x K / K x N
-    # corners are rewritten -- no allocation, no zero fill, no workspace set-up per call
-    b['V'][:F, :N].copy_(torch.from_numpy(np.ascontiguousarray(V, dtype=float32)))
+    # the padding of the cached buffers is zero and stays zero (the kernels never write it): no allocation, no zero fill, no workspace
+    # set-up per call.  V goes up and W, H come down as WHOLE padded images through page-locked staging buffers: one contiguous
+    # transfer each at PCIe speed, the corner slicing happens on the host (a strided device slice costs a gather kernel plus a pageable
+    # copy: 8.45 -> 8.2 ms per call at K = 1024).
+    b['hV'].numpy()[:F, :N] = V
+    b['V'].copy_(b['hV'], non_blocking=True)
     b['W'][:F, :K].copy_(init['W'])
     b['H'][:K, :N].copy_(init['H'])
     _hip.check(lib.gccnmf_klnmf(_ptr(b['V']), _ptr(b['W']), _ptr(b['H']), _ptr(b['ws']), F, N, K, 1, int(numIterations),
                                 float(sparsityAlpha), float(epsilon), 0, _stream()), 'gccnmf_klnmf')
-    return b['W'][:F, :K].cpu().numpy(), b['H'][:K, :N].cpu().numpy()
+    b['hW'].copy_(b['W'], non_blocking=True)
+    b['hH'].copy_(b['H'], non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return b['hW'].numpy()[:F, :K].copy(), b['hH'].numpy()[:K, :N].copy()
 
 
 # One BIG matrix (the dictionary pre-training set, gccNMF/realtime/gccNMFPretraining.py:79-80: performKLNMF on thousands of frames):
@@ -148,7 +154,9 @@ def _klnmf_buffers(F, N, K, dev):
         g = Geometry(F, 1, K)
         Np = -(-N // 64) * 64
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        b = dict(g=g, V=z(g.Fp, Np), W=z(g.Fp, g.Kp), H=z(g.Kp, Np), ws=z(_hip.lib().gccnmf_klnmf_workspace_floats(F, N, K, 1)), init={})
+        pin = lambda *shape: torch.zeros(shape, dtype=torch.float32).pin_memory()
+        b = dict(g=g, V=z(g.Fp, Np), W=z(g.Fp, g.Kp), H=z(g.Kp, Np), ws=z(_hip.lib().gccnmf_klnmf_workspace_floats(F, N, K, 1)), init={},
+                 hV=pin(g.Fp, Np), hW=pin(g.Fp, g.Kp), hH=pin(g.Kp, Np))
     _KLNMF_BUFFERS[key] = b                      # most recently used last
     while len(_KLNMF_BUFFERS) > 4:
         _KLNMF_BUFFERS.pop(next(iter(_KLNMF_BUFFERS)))

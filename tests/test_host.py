@@ -60,11 +60,13 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 640, 1024, 31, 20032) == Fp * 20032 + 31 * (Fp * Kp + Kp)
     # whole padded files back to back
     assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 64, 0) == 64 * (Fp * 1280 + Fp * Kp + Kp)
-    # ONE file in the plain layout also carries the split-K scratch of the latency path (4 x max(Fp*Np, Fp*Kp) + 4 x Kp)
+    # ONE file in the plain layout also carries the scratch of the latency path: the split-K partials (4 x max(Fp*Np, Fp*Kp) + 4 x Kp)
+    # and the transposed copies Wt | Ht | Rt of the direct kernels
     one = Fp * 1280 + Fp * Kp + Kp
-    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 0) == one + 4 * (Fp * 1280 + Kp)
-    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 1280) == one + 4 * (Fp * 1280 + Kp)
-    assert lib.gccnmf_klnmf_shared_workspace_floats(513, 1244, 1024, 1) == one + 4 * (Fp * 1280 + Kp) + 2 * Kp
+    lat = 4 * (Fp * 1280 + Kp) + Kp * Fp + 1280 * Kp + 1280 * Fp
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 0) == one + lat
+    assert lib.gccnmf_klnmf_shared_shard_workspace_floats(513, 1244, 1024, 1, 1280) == one + lat
+    assert lib.gccnmf_klnmf_shared_workspace_floats(513, 1244, 1024, 1) == one + lat + 2 * Kp
     assert lib.gccnmf_klnmf_shared_partial_floats(513, 1024) == Fp * Kp + Kp
     for bad in [(513, 100, 1024, 2, 640), (513, 640, 1024, 3, 1280), (513, 640, 1024, 1, 642), (513, 0, 1024, 1, 0)]:
         assert lib.gccnmf_klnmf_shared_shard_workspace_floats(*bad) == -1      # ragged block in a batch / blocks beyond ld / pitch % 4 / N = 0
