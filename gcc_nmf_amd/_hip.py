@@ -28,7 +28,7 @@ class DirectGemm(ctypes.Structure):
                 ('Ct', c_void_p), ('sCt', c_long), ('ldct', c_int), ('E0', c_void_p), ('sE0', c_long), ('lde0', c_int),
                 ('E1', c_void_p), ('sE1', c_long), ('E2', c_void_p), ('sE2', c_long), ('ktailA', c_void_p), ('ktailB', c_void_p),
                 ('s_ktailA', c_long), ('s_ktailB', c_long), ('alpha', c_float), ('eps', c_float),
-                ('tiles_m', c_int), ('tiles_n', c_int), ('xc', c_int), ('sm', c_int), ('sn', c_int)]
+                ('tiles_m', c_int), ('tiles_n', c_int), ('xc', c_int), ('sm', c_int), ('sn', c_int), ('trace', c_void_p)]
 
 
 # gccnmf_allreduce_fn: int (*)(void* ctx, float* buf, long count, void* stream)

@@ -23,6 +23,8 @@
 #define DIRECT_MAX_DEVICES 64
 extern int gccnmf_tune_ablate;
 extern int gccnmf_tune_direct_depth;
+extern long long* gccnmf_trace_buf;
+extern int gccnmf_trace_blocks;
 
 typedef float df32x4 __attribute__((ext_vector_type(4)));
 typedef float df32x2 __attribute__((ext_vector_type(2)));
@@ -101,6 +103,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int m0 = tm * TR, n0 = tn * TC;
+    if (p.trace && tid == 0) {      // per-workgroup timeline (gccnmf_debug_set_trace, scripts/ktrace_single.py): same slots as the ring kernel
+        p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    }
     const float* __restrict__ A = p.A + file * p.sA;
     const float* __restrict__ B = p.B + file * p.sB;
     const int nchunks = (p.Kd + 15) >> 4;
@@ -150,27 +156,32 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         if (SC) f.sc = DLoad<4>::ld(rS, 16u * (unsigned)g, 64u * chu);
         if (SIDE) f.tl = DLoad<4>::ld(rT, 16u * (unsigned)g, 64u * chu);
     };
+    // The lazy scale of B per reduction index (K1: H carries the previous normalisation as the vector s) is applied to the A values
+    // instead: s[r] * (A[r][m] * B[r][n]) summed over r is the same product, MB multiplies per step instead of NB, and a wave's own A
+    // values are not shared with anybody (fl(W s) . H rather than W . fl(s H): one rounding per term either way).  Timeline of one
+    // mixture (scripts/ktrace_single.py): the main loop of K1 took 12.8 us with the B-side multiplies, K3 -- the same loop without a
+    // scale -- 10.6.  Row sums of B are taken only where they are asked for (the R.H^T launch), not in every side workgroup.
+    constexpr bool ROWSUM = EPI == DEPI_STORE;
     auto compute = [&](auto side_c, auto sc_c, const Frag& f) {
         constexpr bool SIDE = decltype(side_c)::value, SC = decltype(sc_c)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float bv[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                bv[nb] = nb < 4 * G4 ? f.b4[e][nb < 4 * G4 ? nb / 4 : 0][nb & 3] : dget(f.br[e], nb < 4 * G4 ? 0 : nb - 4 * G4);
-                if (SC) bv[nb] *= f.sc[e];                         // fl(H * s), as every other K1 does
-            }
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = nb < 4 * G4 ? f.b4[e][nb < 4 * G4 ? nb / 4 : 0][nb & 3] : dget(f.br[e], nb < 4 * G4 ? 0 : nb - 4 * G4);
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
-                const float av = dget(f.a[e], j);
+                float av = dget(f.a[e], j);
+                if (SC) av *= f.sc[e];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[j][nb], 0, 0, 0);
             }
             if (SIDE) {
+                const float tv = SC ? f.tl[e] * f.sc[e] : f.tl[e];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    tacc[nb] = fmaf(f.tl[e], bv[nb], tacc[nb]);
-                    racc[nb] += bv[nb];
+                    tacc[nb] = fmaf(tv, bv[nb], tacc[nb]);
+                    if (ROWSUM) racc[nb] += bv[nb];
                 }
             }
         }
@@ -195,6 +206,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         Frag f[NBUF];
 #pragma unroll
         for (int j = 0; j < NBUF - 1; ++j) load(side_c, sc_c, f[j], wave + j * NW);
+        if (p.trace && tid == 0) {
+            p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime();
+        }
         int it = 0;
         for (; it + NBUF <= niter; it += NBUF) {
 #pragma unroll
@@ -227,6 +242,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         else main_loop(std::false_type{}, std::false_type{});
     }
 
+    if (p.trace && tid == 0) {
+        p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memtime();
+    }
     // ---- epilogue ----------------------------------------------------------------------------------------------------
     // what the element-wise part needs from global memory is requested before the partial tiles are exchanged
     const long fC = file * p.sC;
@@ -347,6 +366,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
             if (p.rowsumB) p.rowsumB[file * p.s_rowsumB + col] = r;
         }
     }
+    if (p.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- launch --------------------------------------------------------------------------------------------------------------
@@ -433,6 +457,7 @@ int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream) {
     if ((epi == DEPI_DIV || epi == DEPI_DIVT) && (!a.E0 || (a.lde0 & 3))) return GCCNMF_ERR_ARG;
     if (epi == DEPI_UPDH && !a.E2) return GCCNMF_ERR_ARG;
     if (a.tailA && !a.C) return GCCNMF_ERR_ARG;
+    if (a.bscale && epi != DEPI_DIV) return GCCNMF_ERR_ARG;            // the lazy scale exists in the K1 form only
     const int t = tile > 0 ? tile - 1 : direct_pick_tile(a);
     if (t < 0 || t >= direct_ntiles) return GCCNMF_ERR_ARG;
     const int TR = 16 * direct_tiles[t].mb, TC = 16 * direct_tiles[t].nb;
@@ -448,6 +473,8 @@ int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream) {
             a.xc = xc; a.sm = sm; a.sn = sn;
         }
     }
+    const long grid = (long)a.batch * 8 * a.sm * a.sn;
+    a.trace = (gccnmf_trace_buf && grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;
     switch (epi) {
         case DEPI_STORE: return direct_launch_e<DEPI_STORE>(a, t, stream);
         case DEPI_DIV: return direct_launch_e<DEPI_DIV>(a, t, stream);

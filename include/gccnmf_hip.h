@@ -316,7 +316,7 @@ int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);
 /* Latency-path GEMM with the KL-NMF element-wise work fused (csrc/direct.hip): what gccnmf_klnmf runs for ONE mixture alone
  * (performKLNMF(V (513, 1244), 1024, 100, 0) is four of these + the W update per iteration), exported so that it can be tested
  * and timed in isolation.
- *     C[m][n] = sum_r A[r][m] * (bscale[r] *) B[r][n]        r < Kd, m < M, n < N
+ *     C[m][n] = sum_r (bscale[r] *) A[r][m] * B[r][n]        r < Kd, m < M, n < N      (bscale: epilogue 1 only, else NULL)
  * BOTH operands are reduction-major: one reduction index per row (pitches lda / ldb, multiples of 4), the output index contiguous
  * -- rows r < round_up(Kd, 16) must be addressable, and zero beyond Kd in at least one operand.  Every pointer is device memory;
  * per-file strides (s*) are in floats.  epilogue (numpy.dot / element-wise lines of gccNMFFunctions.py:76-77):
@@ -327,7 +327,7 @@ int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);
  * tailA != NULL adds output row `tail_row` = sum_r tailA[r] * B[r][n], computed on the VALU (F = 513 = 16 * 32 + 1), with the
  * epilogue applied (it goes to C, and to Ct as well for DIVT).  Nothing outside the M x N corner (plus the tail row) is written,
  * except zeros inside a 4-float group that straddles it.  tile: 0 = chosen by the library, 1..8 = a fixed tile (experiments).
- * The trailing five fields are filled in by the library. */
+ * The trailing six fields are filled in by the library. */
 typedef struct gccnmf_direct_gemm {
     const float* A;
     const float* B;
@@ -359,6 +359,7 @@ typedef struct gccnmf_direct_gemm {
     long s_ktailA, s_ktailB;
     float alpha, eps;
     int tiles_m, tiles_n, xc, sm, sn;
+    long long* trace;          /* library-filled: per-workgroup timeline while gccnmf_debug_set_trace is armed */
 } gccnmf_direct_gemm;
 int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream);
 
