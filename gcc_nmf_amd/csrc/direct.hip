@@ -272,6 +272,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         }
     }
 
+    float vtail = 1.f;                  // numerator of the tail-row element this thread will finish (requested now, used after the exchange)
+    if ((EPI == DEPI_DIV || EPI == DEPI_DIVT) && side && p.tailA && tid < TC)
+        vtail = p.E0[file * p.sE0 + (long)p.tail_row * p.lde0 + min(n0 + tid, p.N - 1)];
     // the wave's copy of the tile -> LDS: accumulator register i of block (j, nb) is row MB * (4g + i) + j, column 4c + (nb % 4) of
     // column group nb / 4 (one 16-byte store per group)
     {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gccnmf_direct_kernel(const DirectA
         if (col < p.N) {
             if (p.tailA) {
                 float o = t;
-                if (EPI == DEPI_DIV || EPI == DEPI_DIVT) o = p.E0[file * p.sE0 + (long)p.tail_row * p.lde0 + col] / t;
+                if (EPI == DEPI_DIV || EPI == DEPI_DIVT) o = vtail / t;
                 p.C[fC + (long)p.tail_row * p.ldc + col] = o;
                 if (EPI == DEPI_DIVT) p.Ct[file * p.sCt + (long)col * p.ldct + p.tail_row] = o;
             }
