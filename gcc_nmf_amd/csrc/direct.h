@@ -23,6 +23,10 @@ typedef gccnmf_direct_gemm DirectArgs;
 // epi: DirectEpilogue.  tile: 0 = chosen by the cost model, 1.. = index into the tile table (experiments).  Returns a GCCNMF_* status.
 int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream);
 
+// K1 + K2 of one iteration in one launch for short dictionaries (K <= 256, one row tile): A = Wt, A2 = W, B = H, C = H (in place), E0 = V,
+// E1 = bscale = the lazy row scale, E2 = colsum W; M = F - 1 (bin M is the tail row of A2).  GCCNMF_ERR_UNSUPPORTED outside its shapes.
+int gccnmf_wh_updh_launch(DirectArgs a, hipStream_t stream);
+
 // out[c][r] = in[r][c] for r < rows, c < cols (batched; strides in floats) -- the transposed copies the direct path starts from
 int gccnmf_transpose_launch(const float* in, long s_in, int ld_in, float* out, long s_out, int ld_out, int rows, int cols, int batch,
                             hipStream_t stream);

@@ -616,6 +616,240 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream) {
     return GCCNMF_OK;
 }
 
+// ---- K1 and K2 of one KL-NMF iteration in ONE launch, for short dictionaries (round 4) ----------------------------------------------
+//   R = V / (W . (s*H))   then   H = (s*H) * (W^T . R) / (colsum W + alpha + eps)            (gccNMFFunctions.py:76)
+// At K = 128 (the reference driver's default, runGCCNMF.py:41) the two throughput launches are bound by what they move, not by the matrix
+// cores: K1 writes R (2.7 MB per file) only for K2 to read it back, and both are 8 k-tiles of main loop against a 12 us epilogue
+// (64 files: 134 + 95 us against an MFMA floor of 2 x 66).  One row tile covers all F - 1 = 512 bins, so a workgroup (512 x 64, four
+// waves of 128 x 64 like the throughput tile) holds ALL of R for its 64 columns in its accumulators when K1 ends -- exactly what W^T . R
+// needs for those columns.  The second product therefore runs in the same workgroup, and R never leaves the registers:
+//   * v_mfma_f32_32x32x2_f32 leaves D[row (r&3) + 8 (r>>2) + 4 (lane>>5)][column lane&31] in register r.  Read as a B operand
+//     (B[k = lane>>5][j = lane&31]) register r IS a valid pair of reduction rows (f, f + 4) for the same 32 columns: the accumulators of
+//     K1 feed the MFMAs of K2 as they are, no LDS, no shuffle, no copy;
+//   * the A operand of that step is W [f][atom block] (32 consecutive atoms per lane half, 128 contiguous bytes per row);
+//   * each wave reduces over its own 128 rows, so the four waves' partial 32 x 64 atom blocks meet in LDS (wave order: deterministic),
+//     where the tail bin (a rank-1 term), the lazy scale and the denominator are applied and H is rewritten in place.
+// K1 itself is LDS-free as well: row-major W [f][k] IS the A operand when the k index a lane half owns is 4 consecutive atoms (one
+// 16-byte load per lane and 32 rows: MFMA step s of a chunk of 8 atoms multiplies atoms (k0 + s, k0 + 4 + s)), H rows come one float per
+// lane, the lazy scale sits on the A values.  The order of the sum over k is a property of this kernel (fixed, the same for every file and
+// batch size).  Requirements: one row tile (M <= 512, M % 128 == 0, bin M = the VALU tail), Kd <= 256, lda % 4 == 0.
+__device__ __forceinline__ float direct_div_fast(float v, float d) {      // v / d: v_rcp_f32 + one Newton step through the exact residual
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = v * r;
+    return fmaf(fmaf(-d, q, v), r, q);
+}
+
+template <int NBUF>
+__global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs p) {
+    constexpr int BN = 64, RW = 128, CK = 8, RP = 68;          // chunk = 8 atoms = 4 MFMA steps of 2; RP: pitch of a partial atom block
+    __shared__ __attribute__((aligned(16))) float s_red[2][4][32][RP];      // partial atom blocks of the four waves, double-buffered
+    __shared__ float s_tailp[4][BN];                            // tail bin: partial dot products
+    __shared__ float s_rtail[BN];                               // R[tail bin][col]
+    const int tiles = p.tiles_n;
+    int file = blockIdx.x / tiles, tn = blockIdx.x - file * tiles;
+    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major tile list (blocks b, b + 8, ... run on XCD b % 8)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, idx = xcd * p.xc + slot;
+        if (idx >= p.batch * tiles) return;
+        file = idx / tiles;
+        tn = idx - file * tiles;
+    }
+    file = __builtin_amdgcn_readfirstlane(file);
+    tn = __builtin_amdgcn_readfirstlane(tn);
+    const int col0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_w = wave * RW;
+    const bool wave_active = row_w < p.M;
+    const float* __restrict__ W = p.A + file * p.sA;            // [M + 1][lda]
+    const float* __restrict__ H = p.B + file * p.sB;            // [Kd][ldb]
+    const float* __restrict__ sc = p.bscale + file * p.s_bscale;      // the pending H row scale (always present on this path)
+    const int nchunks = (p.Kd + CK - 1) / CK;
+    const unsigned chunkB = 4u * CK * (unsigned)p.ldb;
+    const __amdgpu_buffer_rsrc_t rW = direct_rsrc(W, 4u * (unsigned)(p.M + 1) * (unsigned)p.lda);
+    const __amdgpu_buffer_rsrc_t rB = direct_rsrc(H, (unsigned)nchunks * chunkB);
+    const __amdgpu_buffer_rsrc_t rS = direct_rsrc(sc, 4u * (unsigned)p.Kd);           // atoms >= Kd read as scale 0
+    unsigned offA[4], offB0[4], offB1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        offA[s] = 4u * (unsigned)(min(row_w + 32 * s + l31, p.M) * p.lda + 4 * hh);             // s = row block m here
+        offB0[s] = 4u * (unsigned)((4 * hh + s) * p.ldb + min(col0 + l31, p.ldb - 1));
+        offB1[s] = 4u * (unsigned)((4 * hh + s) * p.ldb + min(col0 + 32 + l31, p.ldb - 1));
+    }
+    // ---- K1: acc[m][n][r] = (W . (s*H))[row_w + 32 m + (r&3) + 8 (r>>2) + 4 hh][col0 + 32 n + l31]
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    struct Frag {
+        df32x4 a[4], s;
+        float b0[4], b1[4];
+    };
+    auto load = [&](Frag& f, int ch) {
+        const unsigned chu = (unsigned)__builtin_amdgcn_readfirstlane(min(ch, nchunks - 1));
+        const unsigned sb = chu * chunkB, sk = 4u * CK * chu;
+        f.s = DLoad<4>::ld(rS, 16u * (unsigned)hh, sk);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f.a[s] = DLoad<4>::ld(rW, offA[s], sk);
+            f.b0[s] = DLoad<1>::ld(rB, offB0[s], sb);
+            f.b1[s] = DLoad<1>::ld(rB, offB1[s], sb);
+        }
+    };
+    auto compute = [&](const Frag& f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float av = f.a[m][s] * f.s[s];               // the lazy H row scale, on the wave's own A values
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b0[s], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b1[s], acc[m][1], 0, 0, 0);
+            }
+    };
+    if (wave_active) {
+        Frag f[NBUF];
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j) load(f[j], j);
+        int it = 0;
+        for (; it + NBUF <= nchunks; it += NBUF) {
+#pragma unroll
+            for (int j = 0; j < NBUF; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                load(f[(j + NBUF - 1) % NBUF], it + j + NBUF - 1);
+                compute(f[j]);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NBUF - 1; ++j)
+            if (it + j < nchunks) compute(f[j]);
+    }
+    // ---- the tail bin (row M of W, on the VALU): 4 thread groups x Kd / 4 atoms each, then R[M][col] = V[M][col] / sum
+    {
+        const int c = tid & 63, q = tid >> 6;
+        const int col = min(col0 + c, p.ldb - 1);
+        const int per = (p.Kd + 3) >> 2, k0 = q * per, k1 = min(k0 + per, p.Kd);
+        const float* __restrict__ wt = W + (long)p.M * p.lda;
+        float t = 0.f;
+        for (int k = k0; k < k1; ++k) t = fmaf(wt[k] * sc[k], H[(long)k * p.ldb + col], t);
+        s_tailp[q][c] = t;
+    }
+    __syncthreads();
+    if (tid < BN) {
+        const float t = (s_tailp[0][tid] + s_tailp[1][tid]) + (s_tailp[2][tid] + s_tailp[3][tid]);
+        const int col = col0 + tid;
+        s_rtail[tid] = col < p.N ? p.E0[file * p.sE0 + (long)p.M * p.lde0 + col] / t : 0.f;
+    }
+    // ---- R in place: acc = V / acc on the valid columns, 0 elsewhere (R is a reduction operand from here on).  Rows are addressed as a
+    // wave-uniform scalar offset (row_w + 32 m + (r&3) + 8 (r>>2)) * pitch plus ONE per-lane offset (the lane half's 4 rows and the column)
+    const bool oka = col0 + l31 < p.N, okb = col0 + 32 + l31 < p.N;
+    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(p.E0 + file * p.sE0, 4u * (unsigned)(p.M + 1) * (unsigned)p.lde0);
+    const unsigned voVa = 4u * (unsigned)(4 * hh * p.lde0 + min(col0 + l31, p.lde0 - 1));
+    const unsigned voVb = 4u * (unsigned)(4 * hh * p.lde0 + min(col0 + 32 + l31, p.lde0 - 1));
+    const unsigned voW = 4u * (unsigned)(4 * hh * p.lda + l31);
+    if (wave_active) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float xa[16], xb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned so = 4u * (unsigned)((row_w + 32 * m + (r & 3) + 8 * (r >> 2)) * p.lde0);
+                xa[r] = DLoad<1>::ld(rV, voVa, so);
+                xb[r] = DLoad<1>::ld(rV, voVb, so);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[m][0][r] = oka ? direct_div_fast(xa[r], acc[m][0][r]) : 0.f;
+                acc[m][1][r] = okb ? direct_div_fast(xb[r], acc[m][1][r]) : 0.f;
+            }
+        }
+    }
+    // ---- K2: per block of 32 atoms, partial (W^T . R) over this wave's 128 rows with the accumulators of K1 as B operands
+    const int nab = (p.Kd + 31) >> 5;
+    const int al = tid >> 3, cg = 8 * (tid & 7);                  // finishing thread: atom al of the block, columns cg .. cg + 7
+    float* Hout = p.C + file * p.sC;
+    for (int ab = 0; ab < nab; ++ab) {
+        f32x16 u0, u1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u0[r] = u1[r] = 0.f;
+        if (wave_active) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float a[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    a[r] = DLoad<1>::ld(rW, voW, 4u * (unsigned)((row_w + 32 * m + (r & 3) + 8 * (r >> 2)) * p.lda + 32 * ab));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[m][0][r], u0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[m][1][r], u1, 0, 0, 0);
+                }
+            }
+        }
+        // what the finishing step needs from global memory is requested before the exchange
+        const int atom = 32 * ab + al;
+        const int arow = min(atom, p.Kd - 1);
+        const df32x4 h0 = *(const df32x4*)(Hout + (long)arow * p.ldc + col0 + cg), h1 = *(const df32x4*)(Hout + (long)arow * p.ldc + col0 + cg + 4);
+        const float s_at = sc[arow];
+        const float rd = 1.0f / (p.E2[file * p.sE2 + arow] + p.alpha + p.eps);
+        const float wt_at = W[(long)p.M * p.lda + arow];
+        float (*red)[32][RP] = s_red[ab & 1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int a_l = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            red[wave][a_l][l31] = u0[r];
+            red[wave][a_l][32 + l31] = u1[r];
+        }
+        __syncthreads();
+        if (atom < p.Kd) {
+            df32x4 o[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                df32x4 u = *(const df32x4*)&red[0][al][cg + 4 * v];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) u += *(const df32x4*)&red[w][al][cg + 4 * v];
+                const df32x4 rt = *(const df32x4*)&s_rtail[cg + 4 * v];
+                const df32x4 h = v ? h1 : h0;
+                o[v] = df32x4{(h.x * s_at) * (fmaf(wt_at, rt.x, u.x) * rd), (h.y * s_at) * (fmaf(wt_at, rt.y, u.y) * rd),
+                              (h.z * s_at) * (fmaf(wt_at, rt.z, u.z) * rd), (h.w * s_at) * (fmaf(wt_at, rt.w, u.w) * rd)};
+                const int c = col0 + cg + 4 * v;                 // columns >= N: H is zero there and stays zero
+                o[v].x = c < p.N ? o[v].x : 0.f;
+                o[v].y = c + 1 < p.N ? o[v].y : 0.f;
+                o[v].z = c + 2 < p.N ? o[v].z : 0.f;
+                o[v].w = c + 3 < p.N ? o[v].w : 0.f;
+                if (c < p.N) *(df32x4*)(Hout + (long)atom * p.ldc + c) = o[v];
+            }
+        }
+        // (the other buffer of s_red is free again: its readers passed this block's barrier after finishing the block before)
+    }
+}
+
+// A = W [batch][M + 1][lda] (row M = the tail bin), B = C = H [batch][Kd][ldb] (updated in place), E0 = V, bscale = the pending H scale,
+// E2 = colsum W, alpha, eps.
+int gccnmf_wh_updh_launch(DirectArgs a, hipStream_t stream) {
+    if (!a.A || !a.B || !a.C || !a.E0 || !a.E2 || !a.bscale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
+    if (a.M < 128 || a.M > 512 || (a.M & 127) || a.Kd < 1 || a.Kd > 256 || (a.lda & 3) || (a.ldc & 3)) return GCCNMF_ERR_UNSUPPORTED;
+    a.tiles_m = 1;
+    a.tiles_n = gccnmf_ceil_div(a.N, 64);
+    int grid = a.batch * a.tiles_n;
+    a.xc = 0;
+    if (a.batch >= 8) {
+        a.xc = gccnmf_ceil_div(a.batch * a.tiles_n, 8);          // tiles per XCD
+        grid = 8 * a.xc;
+    }
+    if (gccnmf_tune_direct_depth == 3) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gccnmf_wh_updh_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
 // ---- transposed copies ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gccnmf_transpose_kernel(const float* __restrict__ in, long s_in, int ld_in, float* __restrict__ out,
                                                                long s_out, int ld_out, int rows, int cols) {

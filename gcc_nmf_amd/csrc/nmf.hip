@@ -33,6 +33,7 @@ int gccnmf_tune_direct_batch = 4;  // key 12: largest batch that takes the direc
                                    // kernel, 8 files 41.5 / 41.3, 12 files 61.9 / 59.3)
 int gccnmf_tune_fft_r16 = 1;       // key 15: 1 (default) = the offline STFT / iSTFT run up to four radix-2 stages per LDS round trip (fft_core.h)
 int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
+int gccnmf_tune_fused_k12 = 0;     // key 16: 1 = short dictionaries (K <= 256, one row tile) run K1 and K2 as ONE launch, R kept in registers (direct.hip)
 int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
@@ -83,6 +84,10 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 14 && (value == 0 || value == 1)) {
         gccnmf_tune_short_updh = value;
+        return GCCNMF_OK;
+    }
+    if (key == 16 && (value == 0 || value == 1)) {
+        gccnmf_tune_fused_k12 = value;
         return GCCNMF_OK;
     }
     if (key == 13 && (value == 0 || (value >= 2 && value <= 4))) {
@@ -715,6 +720,25 @@ static int direct_rht(const NmfGeom& g, const DirectBufs& d, const float* R, flo
     return gccnmf_direct_launch(a, DEPI_STORE, gccnmf_tune_direct_tile, s);
 }
 
+// Short dictionaries (K <= 256 -- the reference driver's K = 128): K1 and K2 as ONE launch (gccnmf_wh_updh_kernel), R never written
+static bool fused_wh_updh(const NmfGeom& g, int batch) {
+    return gccnmf_tune_fused_k12 && gccnmf_tune_tile_policy == 0 && !direct_path(g, batch) && batch > 1 && g.tail && g.Fm >= 128 &&
+           g.Fm <= 512 && (g.Fm % 128) == 0 && g.K <= 256;
+}
+static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, float* H, const float* hscale, const float* colsumW, float alpha,
+                          float eps, int batch, hipStream_t s) {
+    DirectArgs a = {};
+    a.A = W; a.sA = g.sW; a.lda = g.Kp;
+    a.B = H; a.sB = g.sH; a.ldb = g.ld;
+    a.M = g.Fm; a.N = g.N; a.Kd = g.K; a.batch = batch;
+    a.bscale = hscale; a.s_bscale = g.Kp;
+    a.C = H; a.sC = g.sH; a.ldc = g.ld;
+    a.E0 = V; a.sE0 = g.sV; a.lde0 = g.ld;
+    a.E2 = colsumW; a.sE2 = g.Kp;
+    a.alpha = alpha; a.eps = eps;
+    return gccnmf_wh_updh_launch(a, s);
+}
+
 extern "C" {
 
 // R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
@@ -775,9 +799,12 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             hipLaunchKernelGGL(nmf_prepare_kernel, dim3(vec_grid), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
             break;
         case 1:
+            if (fused_wh_updh(g, batch)) return launch_wh_updh(g, V, W, H, hscale, colsumW, alpha, eps, batch, s);      // K1 + K2
             if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
-        case 2: return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
+        case 2:
+            if (fused_wh_updh(g, batch)) return GCCNMF_OK;                                                             // done by stage 1
+            return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
         case 3:
             if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);

@@ -15,6 +15,7 @@ from oracle import gccnmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip('torch')
+FUSED_K12_DEFAULT = 0       # library default of tuning key 16
 
 
 @pytest.fixture(scope='module')
@@ -449,6 +450,43 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
             # the padding stays exactly zero (it is a reduction operand)
             assert not W[b, F:].any() and not W[b, :, K:].any() and not H[b, K:].any() and not H[b, :, 2 * T:].any(), (name, b)
     assert rel(res['direct'][0], res['split'][0]) < 2e-5
+
+
+@pytest.mark.parametrize('F,T,K,B,alpha', [(513, 75, 128, 6, 0.0), (513, 40, 200, 9, 0.2), (257, 33, 100, 5, 0.0), (385, 20, 64, 12, 0.0),
+                                           (513, 330, 128, 13, 0.0)])
+def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
+    """Short dictionaries (K <= 256, the reference driver's K = 128: runGCCNMF.py:41): K1 + K2 of an iteration as ONE launch with R kept in
+    the accumulators (tuning key 16, csrc/direct.hip gccnmf_wh_updh_kernel) against the two-launch form and the oracle; the padding
+    of W and H stays exactly zero; a file's bits do not depend on the batch."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
+    N = 2 * T
+    g = Geometry(F, T, K)
+    rng = np.random.RandomState(F + K + B)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    res = {}
+    try:
+        for name, k16, files in [('two-launch', 0, list(range(B))), ('fused', 1, list(range(B))), ('fused-some', 1, [B - 1, 0, 2, 1, 3])]:
+            assert lib.gccnmf_set_tuning(16, k16) == 0
+            b = len(files)
+            Vd = padded(V[files], (b, g.Fp, g.Np), 'cuda')
+            Wd = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
+            Hd = padded(np.repeat(H0[None], b, 0), (b, g.Kp, g.Np), 'cuda')
+            ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, b), dtype=torch.float32, device='cuda')
+            assert lib.gccnmf_klnmf(Vd.data_ptr(), Wd.data_ptr(), Hd.data_ptr(), ws.data_ptr(), F, N, K, b, 6, alpha, 1e-16, 0, stream()) == 0
+            torch.cuda.synchronize()
+            res[name] = (Wd.cpu().numpy(), Hd.cpu().numpy())
+    finally:
+        lib.gccnmf_set_tuning(16, FUSED_K12_DEFAULT)
+    for name in ('two-launch', 'fused'):
+        W, H = res[name]
+        assert not W[:, F:].any() and not W[:, :, K:].any() and not H[:, K:].any() and not H[:, :, N:].any(), name
+        for b in (0, B - 1):
+            Wr, Hr = O.performKLNMF(V[b], K, 6, alpha)
+            assert rel(W[b, :F, :K], Wr) < 1e-4 and rel(H[b, :K, :N], Hr) < 1e-4, (name, b, rel(W[b, :F, :K], Wr), rel(H[b, :K, :N], Hr))
+    assert rel(res['fused'][0], res['two-launch'][0]) < 2e-5 and rel(res['fused'][1], res['two-launch'][1]) < 2e-5
+    assert np.array_equal(res['fused-some'][0][0], res['fused'][0][B - 1]) and np.array_equal(res['fused-some'][1][2], res['fused'][1][2])
 
 
 def hip_geometry(F, T, K):
