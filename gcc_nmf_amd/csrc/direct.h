@@ -23,9 +23,32 @@ typedef gccnmf_direct_gemm DirectArgs;
 // epi: DirectEpilogue.  tile: 0 = chosen by the cost model, 1.. = index into the tile table (experiments).  Returns a GCCNMF_* status.
 int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream);
 
-// K1 + K2 of one iteration in one launch for short dictionaries (K <= 256, one row tile): A = Wt, A2 = W, B = H, C = H (in place), E0 = V,
-// E1 = bscale = the lazy row scale, E2 = colsum W; M = F - 1 (bin M is the tail row of A2).  GCCNMF_ERR_UNSUPPORTED outside its shapes.
-int gccnmf_wh_updh_launch(DirectArgs a, hipStream_t stream);
+// K1 + K2 of one iteration in one launch for short dictionaries (Kd <= 256, one row tile of M = F - 1 <= 512 rows; bin M rides on the VALU):
+//   H <- (scale*H) * (W^T . (V / (W . (scale*H)))) / (colsum + alpha + eps), R never written.  Wt = k-major copy of W (K1's A operand).
+struct WhUpdhArgs {
+    const float *Wt, *W, *H, *V, *scale, *colsum;
+    float* Hout;                // == H (updated in place)
+    long sWt, sW, sH, sV, sVec; // per-file strides (floats)
+    int ldwt, lda, ldb, ldv;    // row pitches of Wt, W, H, V
+    int M, N, Kd, batch;
+    float alpha, eps;
+    int tiles_n, xc;            // filled in by the launcher
+    long long* trace;
+};
+int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream);
+
+// K3 + K4a of one iteration in one launch for short dictionaries (Kd <= 128, M = F - 1 <= 512 a multiple of 64; bin M on the VALU):
+//   U = (V / (W . H)) . H^T and rowsumH = sum_n H, R never written (workgroup = 64-bin slab of a file, W rows resident in registers)
+struct WhdivRhtArgs {
+    const float *W, *H, *V;
+    float *U, *rowsumH;
+    long sW, sH, sV, sU, sVec;  // per-file strides (floats)
+    int lda, ldb, ldv, ldu;     // row pitches of W, H, V, U
+    int M, N, Kd, batch;
+    int nslabs, xc;             // filled in by the launcher
+    long long* trace;
+};
+int gccnmf_whdiv_rht_launch(WhdivRhtArgs a, hipStream_t stream);
 
 // out[c][r] = in[r][c] for r < rows, c < cols (batched; strides in floats) -- the transposed copies the direct path starts from
 int gccnmf_transpose_launch(const float* in, long s_in, int ld_in, float* out, long s_out, int ld_out, int rows, int cols, int batch,

@@ -640,7 +640,7 @@ __device__ __forceinline__ float direct_div_fast(float v, float d) {      // v /
 }
 
 template <int NBUF>
-__global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs p) {
+__global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs p) {
     constexpr int BN = 64, RW = 128, CK = 8, RP = 68;          // chunk = 8 atoms = 4 MFMA steps of 2; RP: pitch of a partial atom block
     __shared__ __attribute__((aligned(16))) float s_red[2][4][32][RP];      // partial atom blocks of the four waves, double-buffered
     __shared__ float s_tailp[4][BN];                            // tail bin: partial dot products
@@ -660,22 +660,29 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row_w = wave * RW;
     const bool wave_active = row_w < p.M;
-    const float* __restrict__ W = p.A + file * p.sA;            // [M + 1][lda]
-    const float* __restrict__ H = p.B + file * p.sB;            // [Kd][ldb]
-    const float* __restrict__ sc = p.bscale + file * p.s_bscale;      // the pending H row scale (always present on this path)
+    if (p.trace && tid == 0) {      // per-workgroup timeline (gccnmf_debug_set_trace, scripts/ktrace_fused.py)
+        p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    }
+    const float* __restrict__ Wt = p.Wt + file * p.sWt;         // [Kd][ldwt]  (k-major copy: the A operand of K1)
+    const float* __restrict__ W = p.W + file * p.sW;            // [M + 1][lda]
+    const float* __restrict__ H = p.H + file * p.sH;            // [Kd][ldb]
+    const float* __restrict__ sc = p.scale + file * p.sVec;     // the pending H row scale (always present on this path)
     const int nchunks = (p.Kd + CK - 1) / CK;
-    const unsigned chunkB = 4u * CK * (unsigned)p.ldb;
+    const unsigned chunkA = 4u * CK * (unsigned)p.ldwt, chunkB = 4u * CK * (unsigned)p.ldb;
+    const __amdgpu_buffer_rsrc_t rA = direct_rsrc(Wt, (unsigned)nchunks * chunkA);
     const __amdgpu_buffer_rsrc_t rW = direct_rsrc(W, 4u * (unsigned)(p.M + 1) * (unsigned)p.lda);
     const __amdgpu_buffer_rsrc_t rB = direct_rsrc(H, (unsigned)nchunks * chunkB);
     const __amdgpu_buffer_rsrc_t rS = direct_rsrc(sc, 4u * (unsigned)p.Kd);           // atoms >= Kd read as scale 0
     unsigned offA[4], offB0[4], offB1[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        offA[s] = 4u * (unsigned)(min(row_w + 32 * s + l31, p.M) * p.lda + 4 * hh);             // s = row block m here
-        offB0[s] = 4u * (unsigned)((4 * hh + s) * p.ldb + min(col0 + l31, p.ldb - 1));
-        offB1[s] = 4u * (unsigned)((4 * hh + s) * p.ldb + min(col0 + 32 + l31, p.ldb - 1));
+    for (int s = 0; s < 4; ++s) {                               // MFMA step s of a chunk multiplies atoms (k0 + 2 s, k0 + 2 s + 1)
+        offA[s] = 4u * (unsigned)((2 * s + hh) * p.ldwt + min(row_w + 4 * l31, p.ldwt - 4));
+        offB0[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + l31, p.ldb - 1));
+        offB1[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + 32 + l31, p.ldb - 1));
     }
-    // ---- K1: acc[m][n][r] = (W . (s*H))[row_w + 32 m + (r&3) + 8 (r>>2) + 4 hh][col0 + 32 n + l31]
+    // ---- K1: acc[m][n][r] = (W . (s*H))[row_w + 4 ((r&3) + 8 (r>>2) + 4 hh) + m][col0 + 32 n + l31]      (interleaved row map: one
+    // 16-byte load of Wt covers the wave's four row blocks)
     f32x16 acc[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -684,18 +691,18 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     struct Frag {
-        df32x4 a[4], s;
-        float b0[4], b1[4];
+        df32x4 a[4];
+        float b0[4], b1[4], s[4];
     };
     auto load = [&](Frag& f, int ch) {
         const unsigned chu = (unsigned)__builtin_amdgcn_readfirstlane(min(ch, nchunks - 1));
-        const unsigned sb = chu * chunkB, sk = 4u * CK * chu;
-        f.s = DLoad<4>::ld(rS, 16u * (unsigned)hh, sk);
+        const unsigned sa = chu * chunkA, sb = chu * chunkB;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            f.a[s] = DLoad<4>::ld(rW, offA[s], sk);
+            f.a[s] = DLoad<4>::ld(rA, offA[s], sa);
             f.b0[s] = DLoad<1>::ld(rB, offB0[s], sb);
             f.b1[s] = DLoad<1>::ld(rB, offB1[s], sb);
+            f.s[s] = DLoad<1>::ld(rS, 4u * (unsigned)(2 * s + hh), 4u * CK * chu);
         }
     };
     auto compute = [&](const Frag& f) {
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const float av = f.a[m][s] * f.s[s];               // the lazy H row scale, on the wave's own A values
+                const float av = f.a[s][m] * f.s[s];               // the lazy H row scale, on the wave's own A values
                 acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b0[s], acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b1[s], acc[m][1], 0, 0, 0);
             }
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
                 load(f[(j + NBUF - 1) % NBUF], it + j + NBUF - 1);
                 compute(f[j]);
 #pragma unroll
-                for (int i = 0; i < 13; ++i) {
+                for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
@@ -731,6 +738,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
         for (int j = 0; j < NBUF - 1; ++j)
             if (it + j < nchunks) compute(f[j]);
     }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();      // K1 main loop done (wave 0)
     // ---- the tail bin (row M of W, on the VALU): 4 thread groups x Kd / 4 atoms each, then R[M][col] = V[M][col] / sum
     {
         const int c = tid & 63, q = tid >> 6;
@@ -738,43 +746,70 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
         const int per = (p.Kd + 3) >> 2, k0 = q * per, k1 = min(k0 + per, p.Kd);
         const float* __restrict__ wt = W + (long)p.M * p.lda;
         float t = 0.f;
-        for (int k = k0; k < k1; ++k) t = fmaf(wt[k] * sc[k], H[(long)k * p.ldb + col], t);
+        for (int kb = k0; kb < k1; kb += 8) {                  // 8 independent loads in flight; atoms >= k1 contribute w = 0
+            float w[8], h[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = min(kb + i, p.Kd - 1);
+                const float wv = wt[k] * sc[k];
+                w[i] = kb + i < k1 ? wv : 0.f;
+                h[i] = H[(long)k * p.ldb + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t = fmaf(w[i], h[i], t);
+        }
         s_tailp[q][c] = t;
     }
     __syncthreads();
     if (tid < BN) {
         const float t = (s_tailp[0][tid] + s_tailp[1][tid]) + (s_tailp[2][tid] + s_tailp[3][tid]);
         const int col = col0 + tid;
-        s_rtail[tid] = col < p.N ? p.E0[file * p.sE0 + (long)p.M * p.lde0 + col] / t : 0.f;
+        s_rtail[tid] = col < p.N ? p.V[file * p.sV + (long)p.M * p.ldv + col] / t : 0.f;
     }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();      // tail bin done
     // ---- R in place: acc = V / acc on the valid columns, 0 elsewhere (R is a reduction operand from here on).  Rows are addressed as a
-    // wave-uniform scalar offset (row_w + 32 m + (r&3) + 8 (r>>2)) * pitch plus ONE per-lane offset (the lane half's 4 rows and the column)
+    // wave-uniform scalar offset (row_w + m + 4 ((r&3) + 8 (r>>2))) * pitch plus ONE per-lane offset (the lane half's 16 rows and the column)
     const bool oka = col0 + l31 < p.N, okb = col0 + 32 + l31 < p.N;
-    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(p.E0 + file * p.sE0, 4u * (unsigned)(p.M + 1) * (unsigned)p.lde0);
-    const unsigned voVa = 4u * (unsigned)(4 * hh * p.lde0 + min(col0 + l31, p.lde0 - 1));
-    const unsigned voVb = 4u * (unsigned)(4 * hh * p.lde0 + min(col0 + 32 + l31, p.lde0 - 1));
-    const unsigned voW = 4u * (unsigned)(4 * hh * p.lda + l31);
+    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(p.V + file * p.sV, 4u * (unsigned)(p.M + 1) * (unsigned)p.ldv);
+    const unsigned voVa = 4u * (unsigned)(16 * hh * p.ldv + min(col0 + l31, p.ldv - 1));
+    const unsigned voVb = 4u * (unsigned)(16 * hh * p.ldv + min(col0 + 32 + l31, p.ldv - 1));
+    const unsigned voW = 4u * (unsigned)(16 * hh * p.lda + l31);
     if (wave_active) {
+        float xa[2][16], xb[2][16];                         // the V tile of row block m + 1 is in flight while block m is divided
+        auto loadv = [&](int m, float* a, float* b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned so = 4u * (unsigned)((row_w + m + 4 * ((r & 3) + 8 * (r >> 2))) * p.ldv);
+                a[r] = DLoad<1>::ld(rV, voVa, so);
+                b[r] = DLoad<1>::ld(rV, voVb, so);
+            }
+        };
+        loadv(0, xa[0], xb[0]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float xa[16], xb[16];
+            __builtin_amdgcn_sched_barrier(0);
+            if (m + 1 < 4) loadv(m + 1, xa[(m + 1) & 1], xb[(m + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const unsigned so = 4u * (unsigned)((row_w + 32 * m + (r & 3) + 8 * (r >> 2)) * p.lde0);
-                xa[r] = DLoad<1>::ld(rV, voVa, so);
-                xb[r] = DLoad<1>::ld(rV, voVb, so);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[m][0][r] = oka ? direct_div_fast(xa[r], acc[m][0][r]) : 0.f;
-                acc[m][1][r] = okb ? direct_div_fast(xb[r], acc[m][1][r]) : 0.f;
+                acc[m][0][r] = oka ? direct_div_fast(xa[m & 1][r], acc[m][0][r]) : 0.f;
+                acc[m][1][r] = okb ? direct_div_fast(xb[m & 1][r], acc[m][1][r]) : 0.f;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();      // R in the accumulators
     // ---- K2: per block of 32 atoms, partial (W^T . R) over this wave's 128 rows with the accumulators of K1 as B operands
     const int nab = (p.Kd + 31) >> 5;
     const int al = tid >> 3, cg = 8 * (tid & 7);                  // finishing thread: atom al of the block, columns cg .. cg + 7
-    float* Hout = p.C + file * p.sC;
+    float* Hout = p.Hout + file * p.sH;
+    float wa[2][16];                                              // W fragments: (atom block, row block) step i + 1 in flight under step i
+    auto loadw = [&](int ab, int m, float* a) {
+        const int abc = min(ab, nab - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = DLoad<1>::ld(rW, voW, 4u * (unsigned)((row_w + m + 4 * ((r & 3) + 8 * (r >> 2))) * p.lda + 32 * abc));
+    };
+    if (wave_active) loadw(0, 0, wa[0]);
     for (int ab = 0; ab < nab; ++ab) {
         f32x16 u0, u1;
 #pragma unroll
@@ -782,23 +817,24 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
         if (wave_active) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                float a[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    a[r] = DLoad<1>::ld(rW, voW, 4u * (unsigned)((row_w + 32 * m + (r & 3) + 8 * (r >> 2)) * p.lda + 32 * ab));
+                __builtin_amdgcn_sched_barrier(0);
+                if (m + 1 < 4) loadw(ab, m + 1, wa[(m + 1) & 1]);
+                else loadw(ab + 1, 0, wa[0]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[m][0][r], u0, 0, 0, 0);
-                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], acc[m][1][r], u1, 0, 0, 0);
+                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m & 1][r], acc[m][0][r], u0, 0, 0, 0);
+                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m & 1][r], acc[m][1][r], u1, 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // what the finishing step needs from global memory is requested before the exchange
         const int atom = 32 * ab + al;
         const int arow = min(atom, p.Kd - 1);
-        const df32x4 h0 = *(const df32x4*)(Hout + (long)arow * p.ldc + col0 + cg), h1 = *(const df32x4*)(Hout + (long)arow * p.ldc + col0 + cg + 4);
+        const df32x4 h0 = *(const df32x4*)(Hout + (long)arow * p.ldb + col0 + cg), h1 = *(const df32x4*)(Hout + (long)arow * p.ldb + col0 + cg + 4);
         const float s_at = sc[arow];
-        const float rd = 1.0f / (p.E2[file * p.sE2 + arow] + p.alpha + p.eps);
+        const float rd = 1.0f / (p.colsum[file * p.sVec + arow] + p.alpha + p.eps);
         const float wt_at = W[(long)p.M * p.lda + arow];
         float (*red)[32][RP] = s_red[ab & 1];
 #pragma unroll
@@ -824,19 +860,18 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const DirectArgs
                 o[v].y = c + 1 < p.N ? o[v].y : 0.f;
                 o[v].z = c + 2 < p.N ? o[v].z : 0.f;
                 o[v].w = c + 3 < p.N ? o[v].w : 0.f;
-                if (c < p.N) *(df32x4*)(Hout + (long)atom * p.ldc + c) = o[v];
+                if (c < p.N) *(df32x4*)(Hout + (long)atom * p.ldb + c) = o[v];
             }
         }
         // (the other buffer of s_red is free again: its readers passed this block's barrier after finishing the block before)
     }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
-// A = W [batch][M + 1][lda] (row M = the tail bin), B = C = H [batch][Kd][ldb] (updated in place), E0 = V, bscale = the pending H scale,
-// E2 = colsum W, alpha, eps.
-int gccnmf_wh_updh_launch(DirectArgs a, hipStream_t stream) {
-    if (!a.A || !a.B || !a.C || !a.E0 || !a.E2 || !a.bscale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
-    if (a.M < 128 || a.M > 512 || (a.M & 127) || a.Kd < 1 || a.Kd > 256 || (a.lda & 3) || (a.ldc & 3)) return GCCNMF_ERR_UNSUPPORTED;
-    a.tiles_m = 1;
+int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream) {
+    if (!a.Wt || !a.W || !a.H || !a.Hout || !a.V || !a.colsum || !a.scale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
+    if (a.M < 128 || a.M > 512 || (a.M & 127) || a.Kd < 1 || a.Kd > 256 || (a.lda & 3) || (a.ldb & 3) || (a.ldwt & 3))
+        return GCCNMF_ERR_UNSUPPORTED;
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     int grid = a.batch * a.tiles_n;
     a.xc = 0;
@@ -844,8 +879,281 @@ int gccnmf_wh_updh_launch(DirectArgs a, hipStream_t stream) {
         a.xc = gccnmf_ceil_div(a.batch * a.tiles_n, 8);          // tiles per XCD
         grid = 8 * a.xc;
     }
+    a.trace = (gccnmf_trace_buf && grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;
     if (gccnmf_tune_direct_depth == 3) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(gccnmf_wh_updh_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// ---- K3 and K4a of one KL-NMF iteration in ONE launch, for short dictionaries (round 4) ---------------------------------------------
+//   R = V / (W . H)   then   U = R . H^T (+ row sums of H)                                   (gccNMFFunctions.py:77, :79)
+// A workgroup owns a SLAB of 64 bins of one file for the whole launch and walks the file's column tiles (64 frames each):
+//   * its rows of W (64 x Kd <= 128) stay in registers for the whole launch (a lane keeps W[f][its 64 atoms]: 64 VGPRs);
+//   * the H tile [Kd][64] of the current frames goes through LDS once (double-buffered, register-staged) and is BOTH operand of the
+//     first product (A = H^T: a lane reads one float of row k) and of the second (A = H: a lane reads four consecutive frames of atom row);
+//   * the first product is computed TRANSPOSED, D'[n][f] = sum_k H[k][n] W[f][k], so that after the divide the accumulator registers are
+//     directly the B operand of U^T[k][f] += sum_n H[k][n] R'[n][f] (register r of a 32x32 accumulator = frame pair (n, n + 4));
+//   * U^T (Kd x 32 bins per wave) accumulates in registers across all column tiles: R is never written, U is written once.
+// Four waves per workgroup: (bin group fg, frame half nh); the two frame halves of a bin group are added at the end (fixed order).
+// The tail bin (row M of W and V) and the row sums of H ride along on the VALU: every slab recomputes r[n] = V[M][n] / (W[M] . H[:, n]) for
+// the tile's frames (16 frames per wave, the atoms dealt over 4 lane groups) and accumulates U[M][k] and rowsumH[k] for ITS OWN 16 atoms
+// -- no reduction across workgroups, no extra launch (needs 16 x slabs >= atoms).
+// 64 files x 8 slabs = 512 workgroups: exactly two per CU, one launch instead of two, no 2.7 MB R round trip per file.
+template <int KB>
+__global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRhtArgs p) {
+    constexpr int P = 68, NCH = 2 * KB, KR = 32 * KB;             // LDS pitch | chunks of 16 atoms | atom rows of the H tile
+    __shared__ __attribute__((aligned(16))) float Hs[2][KR][P];
+    __shared__ float s_w[KR], s_tail[4][4][4][2];
+    const int per_file = p.nslabs;
+    int idx = blockIdx.x;
+    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major workgroup list
+        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
+        if (idx >= p.batch * per_file) return;
+    }
+    const int file = __builtin_amdgcn_readfirstlane(idx / per_file);
+    const int sl = __builtin_amdgcn_readfirstlane(idx - file * per_file);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ W = p.W + file * p.sW;
+    const float* __restrict__ H = p.H + file * p.sH;
+    const float* __restrict__ V = p.V + file * p.sV;
+    float* __restrict__ U = p.U + file * p.sU;
+    const int ntiles = (p.N + 63) >> 6;
+    const __amdgpu_buffer_rsrc_t rH = direct_rsrc(H, 4u * (unsigned)p.Kd * (unsigned)p.ldb);          // atom rows >= Kd read as zero
+    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(V, 4u * (unsigned)(p.M + 1) * (unsigned)p.ldv);
+    // staging: thread (row tid >> 4, float4 tid & 15) moves rows (tid >> 4) + 16 i of the tile, i < 2 KB, in two parts of KB rows each
+    const unsigned st_off = 4u * (unsigned)((tid >> 4) * p.ldb + 4 * (tid & 15));
+    auto stage_load = [&](df32x4 (&r)[KB], int tile, int part) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) r[i] = DLoad<4>::ld(rH, st_off, 4u * (unsigned)(16 * (part * KB + i) * p.ldb + 64 * tile));
+    };
+    auto stage_store = [&](const df32x4 (&r)[KB], int buf, int part) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) *(df32x4*)&Hs[buf][(tid >> 4) + 16 * (part * KB + i)][4 * (tid & 15)] = r[i];
+    };
+    if (p.trace && tid == 0) {
+        p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    }
+    df32x4 h0[KB], h1[KB];
+    stage_load(h0, 0, 0);
+    stage_load(h1, 0, 1);
+
+    // ---- bins f0 .. f0 + 63; wave (fg, nh): bins f0 + 32 fg + l31, frames 32 nh .. 32 nh + 31 of every tile
+    const int fg = wave & 1, nh = wave >> 1;
+    const int f = 64 * sl + 32 * fg + l31;
+    // W resident: w[c][t] = W[f][16 c + 8 hh + t]  (MFMA step t of chunk c multiplies atoms (16 c + t, 16 c + 8 + t))
+    df32x4 w[NCH][2];
+    {
+        const __amdgpu_buffer_rsrc_t rW = direct_rsrc(W, 4u * (unsigned)(p.M + 1) * (unsigned)p.lda);
+        const unsigned wo = 4u * (unsigned)(f * p.lda + 8 * hh);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            w[c][0] = DLoad<4>::ld(rW, wo, 64u * c);
+            w[c][1] = DLoad<4>::ld(rW, wo, 64u * c + 16u);
+        }
+        // atoms >= Kd: the H rows are zero (buffer bound), but W beyond the row's Kp columns is the next row: keep the products finite
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (16 * c + 8 * hh + t >= p.lda) w[c][t >> 2][t & 3] = 0.f;
+    }
+    f32x16 u[KB];
+#pragma unroll
+    for (int ab = 0; ab < KB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[ab][r] = 0.f;
+    stage_store(h0, 0, 0);
+    stage_store(h1, 0, 1);
+    // tail bin: this wave's 16 frames of a tile (frame nl), atoms dealt over the 4 lane groups kq; this slab's atoms 16 sl + 4 kq + i
+    if (tid < KR) s_w[tid] = tid < p.Kd ? W[(long)p.M * p.lda + tid] : 0.f;
+    const int nl = 16 * wave + (lane & 15), kq = lane >> 4;
+    const int a0 = 16 * sl + 4 * kq;
+    const bool tail_atoms = 16 * sl < KR;
+    float um[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned vo = 4u * (unsigned)(f * p.ldv + 32 * nh + 4 * hh);
+    float av[8];
+    df32x4 a4[KB];
+    float pfsum = 0.f, pfv = 0.f, pfh = 0.f;
+    long long tt1 = 0, tt5 = 0, tt6 = 0, tt7 = 0;
+    const unsigned vo_pf = 4u * (unsigned)(f * p.ldv + 32 * nh + 16 * hh);
+    const unsigned ho_pf = 4u * (unsigned)(min(tid >> 1, KR - 1) * p.ldb + 32 * (tid & 1));
+    __syncthreads();
+    for (int c = 0; c < ntiles; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < ntiles;
+        // The tile's instruction order below IS the schedule (scheduling barriers between the small groups keep it):
+        //   first product  (transposed): d[r] = sum_k H[k][n(r)] W[f][k],  n(r) = 64 c + 32 nh + (r&3) + 8 (r>>2) + 4 hh -- one MFMA, then the
+        //     LDS read that refills ITS operand register for the next chunk (7 MFMAs = 450 cycles ahead of its use), four terms of the tail
+        //     bin's dot product per chunk on the VALU;
+        //   half way: the staged rows of the next H tile go to LDS, the second half and this tile's V values are requested;
+        //   second product: U^T[32 ab + i][f] += sum_n H[32 ab + i][n] R'[n][f] -- four MFMAs on one atom block, then the read that refills
+        //     that block's operand for the next four frames; the divides of the next four frames ride in the first group.
+        { const long long now = __builtin_amdgcn_s_memrealtime(); tt1 = c == 8 ? now : tt1; }      // tile 8: start (scalar registers; written out at the end)
+        __builtin_amdgcn_s_setprio(2);                          // the first product is ONE dependent MFMA chain: it yields every other slot anyway
+        if (more) stage_load(h0, c + 1, 0);
+        const float vm = V[(long)p.M * p.ldv + min(64 * c + nl, p.ldv - 1)];
+        df32x4 v[4];
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        float tdot = 0.f, tw[4], th[4];
+        if (c == 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) av[t] = Hs[0][8 * hh + t][32 * nh + l31];
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch == NCH / 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    stage_store(h0, cur ^ 1, 0);
+                    stage_load(h0, c + 1, 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = DLoad<4>::ld(rV, vo, 4u * (unsigned)(64 * c + 8 * j));
+                // L2 prefetch, one dword per cache line: this wave's V lines of the NEXT tile (V is read once, straight from HBM) and this
+                // thread's line of the H tile after the next; the values are only summed (consumed a tile later, when they have long landed)
+                pfsum += pfv + pfh;
+                pfv = more ? DLoad<1>::ld(rV, vo_pf, 4u * (unsigned)(64 * (c + 1))) : 0.f;
+                pfh = c + 2 < ntiles ? DLoad<1>::ld(rH, ho_pf, 4u * (unsigned)(64 * (c + 2))) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w[ch][t >> 2][t & 3], d, 0, 0, 0);
+                if (ch + 1 < NCH) av[t] = Hs[cur][16 * (ch + 1) + 8 * hh + t][32 * nh + l31];
+                if (t < 4) {                                   // tail bin: operands now, the multiply-add four groups later
+                    tw[t] = s_w[kq * (KR / 4) + 4 * ch + t];
+                    th[t] = Hs[cur][kq * (KR / 4) + 4 * ch + t][nl];
+                } else {
+                    tdot = fmaf(tw[t - 4], th[t - 4], tdot);
+                }
+                if (ch == NCH - 1 && t >= 8 - KB) a4[t - (8 - KB)] = *(const df32x4*)&Hs[cur][32 * (t - (8 - KB)) + l31][32 * nh + 4 * hh];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);                          // (the second product's four independent chains would otherwise starve the CU's other workgroup)
+        { const long long now = __builtin_amdgcn_s_memrealtime(); tt5 = c == 8 ? now : tt5; }      // first product issued
+        // tail bin: r[n] for this wave's 16 frames, then U[M][k] and rowsumH[k] of this slab's atoms (while the last MFMAs drain)
+        {
+            tdot += __shfl_xor(tdot, 16);
+            tdot += __shfl_xor(tdot, 32);
+            const float r = 64 * c + nl < p.N ? direct_div_fast(vm, tdot) : 0.f;
+            if (tail_atoms) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float hv = Hs[cur][a0 + i][nl];
+                    um[i] = fmaf(r, hv, um[i]);
+                    rs[i] += hv;
+                }
+            }
+        }
+        auto divide4 = [&](int j) {                            // R' in place (0 beyond the last frame)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 64 * c + 32 * nh + q + 8 * j + 4 * hh;
+                d[4 * j + q] = n < p.N ? direct_div_fast(v[j][q], d[4 * j + q]) : 0.f;
+            }
+        };
+        divide4(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int ab = 0; ab < KB; ++ab) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[ab] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[ab][q], d[4 * j + q], u[ab], 0, 0, 0);
+                if (j + 1 < 4) a4[ab] = *(const df32x4*)&Hs[cur][32 * ab + l31][32 * nh + 8 * (j + 1) + 4 * hh];
+                if (ab == 0 && j + 1 < 4) divide4(j + 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the first operands of the next tile's first product (its rows 0 .. 15 were stored half way through this tile... by ALL threads
+        // only after the next barrier: so they are read at the top of the next tile instead)
+        { const long long now = __builtin_amdgcn_s_memrealtime(); tt6 = c == 8 ? now : tt6; }      // second product issued
+        if (more) stage_store(h0, cur ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            __syncthreads();
+            { const long long now = __builtin_amdgcn_s_memrealtime(); tt7 = c == 8 ? now : tt7; }  // past the barrier
+#pragma unroll
+            for (int t = 0; t < 8; ++t) av[t] = Hs[cur ^ 1][8 * hh + t][32 * nh + l31];
+        }
+    }
+    if (pfsum + pfv + pfh == 1.2345e-31f) U[0] = pfsum;      // (keeps the prefetch loads alive; never true for sums of |V|, H >= 0 data)
+    if (p.trace && tid == 0) {
+        p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+        p.trace[8 * blockIdx.x + 1] = tt1;
+        p.trace[8 * blockIdx.x + 5] = tt5;
+        p.trace[8 * blockIdx.x + 6] = tt6;
+        p.trace[8 * blockIdx.x + 7] = tt7;
+    }
+    // the two frame halves of a bin group meet in LDS (the H tiles are done): nh = 1 writes, nh = 0 adds and stores U[f][atoms]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            um[i] += __shfl_xor(um[i], m);
+            rs[i] += __shfl_xor(rs[i], m);
+        }
+        if ((lane & 15) == 0) {
+            s_tail[wave][kq][i][0] = um[i];
+            s_tail[wave][kq][i][1] = rs[i];
+        }
+    }
+    __syncthreads();
+    if (tid < 16 && tail_atoms) {                                // atom 16 sl + tid: the four waves' frames in wave order
+        const int q = tid >> 2, i = tid & 3, atom = 16 * sl + tid;
+        if (atom < p.ldu) {
+            U[(long)p.M * p.ldu + atom] = (s_tail[0][q][i][0] + s_tail[1][q][i][0]) + (s_tail[2][q][i][0] + s_tail[3][q][i][0]);
+            p.rowsumH[file * p.sVec + atom] = (s_tail[0][q][i][1] + s_tail[1][q][i][1]) + (s_tail[2][q][i][1] + s_tail[3][q][i][1]);
+        }
+    }
+    float* red = &Hs[0][0][0];                                   // [fg][ab][r][lane]
+    if (nh == 1) {
+#pragma unroll
+        for (int ab = 0; ab < KB; ++ab)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((fg * KB + ab) * 16 + r) * 64 + lane] = u[ab][r];
+    }
+    __syncthreads();
+    if (nh == 0) {
+#pragma unroll
+        for (int ab = 0; ab < KB; ++ab)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                df32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = u[ab][4 * j + q] + red[((fg * KB + ab) * 16 + 4 * j + q) * 64 + lane];
+                const int atom = 32 * ab + 8 * j + 4 * hh;
+                if (atom < p.ldu) *(df32x4*)(U + (long)f * p.ldu + atom) = o;
+            }
+    }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+int gccnmf_whdiv_rht_launch(WhdivRhtArgs a, hipStream_t stream) {
+    if (!a.W || !a.H || !a.V || !a.U || !a.rowsumH || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
+    if (a.M < 64 || a.M > 512 || (a.M & 63) || a.Kd < 1 || a.Kd > 128 || (a.lda & 3) || (a.ldb & 3) || (a.ldv & 3) || (a.ldu & 3))
+        return GCCNMF_ERR_UNSUPPORTED;
+    a.nslabs = a.M / 64;
+    if (16 * a.nslabs < 32 * gccnmf_ceil_div(a.Kd, 32)) return GCCNMF_ERR_UNSUPPORTED;      // every atom's tail-bin sum needs a slab
+    const int total = a.batch * a.nslabs;
+    int grid = total;
+    a.xc = 0;
+    if (a.batch >= 8) {
+        a.xc = gccnmf_ceil_div(total, 8);
+        grid = 8 * a.xc;
+    }
+    a.trace = (gccnmf_trace_buf && grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;
+    const int kb = gccnmf_ceil_div(a.Kd, 32);
+    if (kb == 1) hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
+    else if (kb == 2) hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    else if (kb == 3) hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<4>, dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

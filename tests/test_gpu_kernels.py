@@ -15,7 +15,8 @@ from oracle import gccnmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip('torch')
-FUSED_K12_DEFAULT = 0       # library default of tuning key 16
+FUSED_K12_DEFAULT = 0       # library defaults of tuning keys 16 and 17
+FUSED_K34_DEFAULT = 0
 
 
 @pytest.fixture(scope='module')
@@ -455,9 +456,10 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
 @pytest.mark.parametrize('F,T,K,B,alpha', [(513, 75, 128, 6, 0.0), (513, 40, 200, 9, 0.2), (257, 33, 100, 5, 0.0), (385, 20, 64, 12, 0.0),
                                            (513, 330, 128, 13, 0.0)])
 def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
-    """Short dictionaries (K <= 256, the reference driver's K = 128: runGCCNMF.py:41): K1 + K2 of an iteration as ONE launch with R kept in
-    the accumulators (tuning key 16, csrc/direct.hip gccnmf_wh_updh_kernel) against the two-launch form and the oracle; the padding
-    of W and H stays exactly zero; a file's bits do not depend on the batch."""
+    """Short dictionaries (the reference driver's K = 128: runGCCNMF.py:41): K1 + K2 of an iteration as ONE launch with R kept in the
+    accumulators (tuning key 16, K <= 256) and K3 + K4a as ONE launch of 64-bin slabs with their W rows in registers (key 17, K <= 128;
+    csrc/direct.hip) against the four-launch form and the oracle; the padding of W and H stays exactly zero; a file's bits do not
+    depend on the batch."""
     lib = hip.lib()
     from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
     N = 2 * T
@@ -467,8 +469,9 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
     W0, H0 = klnmf_initial_factors(F, N, K)
     res = {}
     try:
-        for name, k16, files in [('two-launch', 0, list(range(B))), ('fused', 1, list(range(B))), ('fused-some', 1, [B - 1, 0, 2, 1, 3])]:
-            assert lib.gccnmf_set_tuning(16, k16) == 0
+        for name, k16, k17, files in [('four-launch', 0, 0, list(range(B))), ('fused-12', 1, 0, list(range(B))), ('fused-34', 0, 1, list(range(B))),
+                                      ('fused', 1, 1, list(range(B))), ('fused-some', 1, 1, [B - 1, 0, 2, 1, 3])]:
+            assert lib.gccnmf_set_tuning(16, k16) == 0 and lib.gccnmf_set_tuning(17, k17) == 0
             b = len(files)
             Vd = padded(V[files], (b, g.Fp, g.Np), 'cuda')
             Wd = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
@@ -479,13 +482,15 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
             res[name] = (Wd.cpu().numpy(), Hd.cpu().numpy())
     finally:
         lib.gccnmf_set_tuning(16, FUSED_K12_DEFAULT)
-    for name in ('two-launch', 'fused'):
+        lib.gccnmf_set_tuning(17, FUSED_K34_DEFAULT)
+    for name in ('four-launch', 'fused-12', 'fused-34', 'fused'):
         W, H = res[name]
+        assert np.isfinite(W).all() and np.isfinite(H).all(), name
         assert not W[:, F:].any() and not W[:, :, K:].any() and not H[:, K:].any() and not H[:, :, N:].any(), name
         for b in (0, B - 1):
             Wr, Hr = O.performKLNMF(V[b], K, 6, alpha)
             assert rel(W[b, :F, :K], Wr) < 1e-4 and rel(H[b, :K, :N], Hr) < 1e-4, (name, b, rel(W[b, :F, :K], Wr), rel(H[b, :K, :N], Hr))
-    assert rel(res['fused'][0], res['two-launch'][0]) < 2e-5 and rel(res['fused'][1], res['two-launch'][1]) < 2e-5
+        assert rel(W, res['four-launch'][0]) < 2e-5 and rel(H, res['four-launch'][1]) < 2e-5, name
     assert np.array_equal(res['fused-some'][0][0], res['fused'][0][B - 1]) and np.array_equal(res['fused-some'][1][2], res['fused'][1][2])
 
 
