@@ -33,7 +33,8 @@ int gccnmf_tune_direct_batch = 4;  // key 12: largest batch that takes the direc
                                    // kernel, 8 files 41.5 / 41.3, 12 files 61.9 / 59.3)
 int gccnmf_tune_fft_r16 = 1;       // key 15: 1 (default) = the offline STFT / iSTFT run up to four radix-2 stages per LDS round trip (fft_core.h)
 int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
-int gccnmf_tune_fused_k34 = 0;     // key 17: 1 = short dictionaries (K <= 128) run K3 and K4a as ONE launch of 64-bin slabs, R never written (direct.hip)
+int gccnmf_tune_fused_k34 = 1;     // key 17: short dictionaries (K <= 128) run K3 and K4a as ONE launch of 64-bin slabs, R never written (direct.hip):
+                                   // 0 never, 1 (default) when its whole rounds of 512 workgroups beat the two launches, 2 whenever the shape allows
 int gccnmf_tune_fused_k12 = 0;     // key 16: 1 = short dictionaries (K <= 256, one row tile) run K1 and K2 as ONE launch, R kept in registers (direct.hip)
 int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
 long long* gccnmf_trace_buf = nullptr;
@@ -91,7 +92,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_fused_k12 = value;
         return GCCNMF_OK;
     }
-    if (key == 17 && (value == 0 || value == 1)) {
+    if (key == 17 && value >= 0 && value <= 2) {
         gccnmf_tune_fused_k34 = value;
         return GCCNMF_OK;
     }
@@ -747,10 +748,18 @@ static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, cons
     return gccnmf_wh_updh_launch(a, s);
 }
 
-// K3 and K4a as ONE launch (gccnmf_whdiv_rht_kernel: 64-bin slabs with their W rows in registers), K <= 128
-static bool fused_whdiv_rht(const NmfGeom& g, int batch) {
-    return gccnmf_tune_fused_k34 && gccnmf_tune_tile_policy == 0 && !direct_path(g, batch) && batch > 1 && g.tail && g.Fm >= 64 && g.Fm <= 512 &&
-           (g.Fm % 64) == 0 && g.K <= 128 && (g.Fm / 64) * 16 >= 32 * gccnmf_ceil_div(g.K, 32);
+// K3 and K4a as ONE launch (gccnmf_whdiv_rht_kernel: 64-bin slabs with their W rows in registers), K <= 128.
+// Every slab workgroup walks ALL column tiles of its file, so the launch costs one "round" (two workgroups per CU, 512 at a time) however
+// few workgroups it holds: measured at K = 128, N = 1244 a round takes 184 us against 3.72 us per file for the two launches it replaces
+// (64 files: 184 against 238 us; 40 files: 184 against 149).  Both scale alike with K and N, so the choice is a ratio: the fused launch
+// runs when batch * slabs / 8 > 49.5 * rounds.  (flags bit 2: another file group of the same size runs beside this one and shares the round.)
+static bool fused_whdiv_rht(const NmfGeom& g, int batch, int flags) {
+    if (!gccnmf_tune_fused_k34 || gccnmf_tune_tile_policy != 0 || direct_path(g, batch) || batch < 2 || !g.tail || g.Fm < 64 || g.Fm > 512 ||
+        (g.Fm % 64) != 0 || g.K > 128 || (g.Fm / 64) * 16 < 32 * gccnmf_ceil_div(g.K, 32))
+        return false;
+    if (gccnmf_tune_fused_k34 == 2) return true;
+    const long slabs = g.Fm / 64, wgs = (long)batch * slabs * ((flags & 4) ? 2 : 1), rounds = (wgs + 511) / 512;
+    return 8 * 495 * rounds < 10 * wgs;
 }
 static int launch_whdiv_rht(const NmfGeom& g, const float* V, const float* W, const float* H, float* U, float* rowsumH, int batch, hipStream_t s) {
     WhdivRhtArgs a = {};
@@ -790,7 +799,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
     float* direct_base = batch == 1 ? rowsum_parts + GCCNMF_SPLITS * (long)g.Kp : parts;
     float* fusedWt = direct_base + direct_floats(g, batch);                       // fused_shape only
-    const bool fused12 = fused_wh_updh(g, batch), fused34 = fused_whdiv_rht(g, batch);
+    const bool fused12 = fused_wh_updh(g, batch), fused34 = fused_whdiv_rht(g, batch, flags);
     if (direct_path(g, batch)) {
         const DirectBufs d = direct_bufs(g, direct_base, batch);
         switch (stage) {

@@ -61,7 +61,12 @@ int gccnmf_version(void);
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..16, default 4).
  * key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4).  key 14: 1 (default) = H updates of at most 128
- * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.  Unknown keys / values: GCCNMF_ERR_ARG. */
+ * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.
+ * keys 16 / 17: short dictionaries (the reference driver's K = 128, runGCCNMF.py:41), F = 128 n + 1 <= 513.  key 17: K3 + K4a of an
+ * iteration as ONE launch of 64-bin slabs that keep their W rows in registers and never write R (K <= 128; csrc/direct.hip): 0 never,
+ * 1 (default) when its whole rounds of 512 workgroups beat the two launches (from about 50 files per round), 2 whenever the shape allows.
+ * key 16: 1 = K1 + K2 as ONE launch with R kept in the accumulators (K <= 256; default 0: measured equal to the two launches).
+ * Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
