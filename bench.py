@@ -404,9 +404,15 @@ def main():
         traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
         iter_ms, k3_ms = kernel_timings(e)
-        flop_per_launch = 2.0 * g.F * g.K * g.N * B                          # algorithmic: F=513, N=2T, not the padded tile grid
+        gemm_flop = 2.0 * g.F * g.K * g.N * B                                # algorithmic: F=513, N=2T, not the padded tile grid
+        # short dictionaries: the library may run K3 + K4a as ONE launch of 64-bin slabs (gccnmf_klnmf_plan bit 2) -- then that launch is
+        # the dominant kernel, and it holds two GEMMs
+        slabs = bool(e.lib.gccnmf_klnmf_plan(g.F, g.N, g.K, e.batch, e.klnmf_flags) & 4)
+        flop_per_launch = (2 if slabs else 1) * gemm_flop
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)',
+        kernel_name = ('gccnmf_whdiv_rht_kernel (K3 + K4a in one launch: U = (V / (W.H)) . H^T, R never written)' if slabs else
+                       'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)')
+        out['roofline'] = {'bound': 'mfma', 'kernel': kernel_name,
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                            'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms),
                            'launch': 'one launch over all %d files on one stream, %d back to back (the timed steps run KL-NMF as %d file '
@@ -419,8 +425,8 @@ def main():
         # one KL-NMF iteration = the four dependent GEMM launches, whole batch on ONE stream, wall time between events: includes
         # the ~40-60 us a kernel boundary costs between dependent launches (the timed steps hide those under the other file
         # group's kernels; kernel-time sums are in the rocprofv3 summaries)
-        out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12,
-                                           'frac_of_peak': 4 * flop_per_launch / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+        out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12,
+                                           'frac_of_peak': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
 
     if rank == 0 and world == 1 and not a.skip_extras:
         # the same parameters on ONE mixture (BASELINE config 2's shape): latency-bound, small-batch GEMM tile

@@ -873,6 +873,14 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     return GCCNMF_OK;
 }
 
+// Which launches gccnmf_klnmf would use for this problem under the current tuning: bit 0 the direct latency kernels, bit 1 the fused
+// K1 + K2 launch, bit 2 the fused K3 + K4a slab launch (benchmarks and tests name the kernel they time by this).
+int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
+    if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
+    const NmfGeom g = make_geom(F, N, K);
+    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch) ? 2 : 0) | (fused_whdiv_rht(g, batch, flags) ? 4 : 0);
+}
+
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
                        float sparsity_alpha, float epsilon, int flags, int stage, void* stream) {
     if (!V || !W || !H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;

@@ -126,6 +126,11 @@ long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch);
 int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
                  int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
 
+/* Which launches gccnmf_klnmf uses for this problem under the current tuning: bit 0 = the direct latency kernels (a handful of files),
+ * bit 1 = K1 + K2 as one launch (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17).  -1 on bad arguments.
+ * (Benchmarks and tests name the kernel they time by this; the result of gccnmf_klnmf does not depend on it beyond round-off.) */
+int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags);
+
 /* One launch group of the iteration on its own (per-kernel tests and per-kernel timing in bench.py).
  * stage: 0 prepare (zero R, colsum W, scale = 1) | 1 R=V/(W.(s*H)) | 2 H update | 3 R=V/(W.H) |
  *        4 U=R.H^T + rowsum H | 5 W update + atom normalisation | 6 materialise H *= s */

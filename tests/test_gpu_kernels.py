@@ -473,6 +473,8 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
                                       ('fused', 1, 2, list(range(B))), ('fused-some', 1, 2, [B - 1, 0, 2, 1, 3])]:
             assert lib.gccnmf_set_tuning(16, k16) == 0 and lib.gccnmf_set_tuning(17, k17) == 0
             b = len(files)
+            if F == 513:                                       # the library reports the launches it will use
+                assert lib.gccnmf_klnmf_plan(F, N, K, b, 0) == (2 if k16 else 0) | (4 if k17 and K <= 128 else 0), name
             Vd = padded(V[files], (b, g.Fp, g.Np), 'cuda')
             Wd = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
             Hd = padded(np.repeat(H0[None], b, 0), (b, g.Kp, g.Np), 'cuda')
