@@ -454,7 +454,7 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
 
 
 @pytest.mark.parametrize('F,T,K,B,alpha', [(513, 75, 128, 6, 0.0), (513, 40, 200, 9, 0.2), (257, 33, 100, 5, 0.0), (385, 20, 64, 12, 0.0),
-                                           (513, 330, 128, 13, 0.0)])
+                                           (513, 330, 128, 13, 0.0), (513, 50, 96, 5, 0.1), (513, 37, 20, 8, 0.0), (129, 64, 32, 5, 0.0)])
 def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
     """Short dictionaries (the reference driver's K = 128: runGCCNMF.py:41): K1 + K2 of an iteration as ONE launch with R kept in the
     accumulators (tuning key 16, K <= 256) and K3 + K4a as ONE launch of 64-bin slabs with their W rows in registers (key 17, K <= 128;
