@@ -976,10 +976,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
     const unsigned vo = 4u * (unsigned)(f * p.ldv + 32 * nh + 4 * hh);
     float av[8];
     df32x4 a4[KB];
-    float pfsum = 0.f, pfv = 0.f, pfh = 0.f;
     long long tt1 = 0, tt5 = 0, tt6 = 0, tt7 = 0;
-    const unsigned vo_pf = 4u * (unsigned)(f * p.ldv + 32 * nh + 16 * hh);
-    const unsigned ho_pf = 4u * (unsigned)(min(tid >> 1, KR - 1) * p.ldb + 32 * (tid & 1));
     __syncthreads();
     for (int c = 0; c < ntiles; ++c) {
         const int cur = c & 1;
@@ -1014,11 +1011,6 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = DLoad<4>::ld(rV, vo, 4u * (unsigned)(64 * c + 8 * j));
-                // L2 prefetch, one dword per cache line: this wave's V lines of the NEXT tile (V is read once, straight from HBM) and this
-                // thread's line of the H tile after the next; the values are only summed (consumed a tile later, when they have long landed)
-                pfsum += pfv + pfh;
-                pfv = more ? DLoad<1>::ld(rV, vo_pf, 4u * (unsigned)(64 * (c + 1))) : 0.f;
-                pfh = c + 2 < ntiles ? DLoad<1>::ld(rH, ho_pf, 4u * (unsigned)(64 * (c + 2))) : 0.f;
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -1083,7 +1075,6 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
             for (int t = 0; t < 8; ++t) av[t] = Hs[cur ^ 1][8 * hh + t][32 * nh + l31];
         }
     }
-    if (pfsum + pfv + pfh == 1.2345e-31f) U[0] = pfsum;      // (keeps the prefetch loads alive; never true for sums of |V|, H >= 0 data)
     if (p.trace && tid == 0) {
         p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
         p.trace[8 * blockIdx.x + 1] = tt1;
