@@ -23,13 +23,14 @@ typedef gccnmf_direct_gemm DirectArgs;
 // epi: DirectEpilogue.  tile: 0 = chosen by the cost model, 1.. = index into the tile table (experiments).  Returns a GCCNMF_* status.
 int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream);
 
-// K1 + K2 of one iteration in one launch for short dictionaries (Kd <= 256, one row tile of M = F - 1 <= 512 rows; bin M rides on the VALU):
-//   H <- (scale*H) * (W^T . (V / (W . (scale*H)))) / (colsum + alpha + eps), R never written.  Wt = k-major copy of W (K1's A operand).
+// K1 + K2 of one iteration in one launch for short dictionaries (Kd <= 128, M = F - 1 <= 512 a multiple of 64; bin M rides on the VALU):
+//   H <- (scale*H) * (W^T . (V / (W . (scale*H)))) / (colsum + alpha + eps), R never written (workgroup = 64-frame column tile of a file,
+//   its scaled H resident in registers, W in 64-bin chunks through LDS)
 struct WhUpdhArgs {
-    const float *Wt, *W, *H, *V, *scale, *colsum;
-    float* Hout;                // == H (updated in place)
-    long sWt, sW, sH, sV, sVec; // per-file strides (floats)
-    int ldwt, lda, ldb, ldv;    // row pitches of Wt, W, H, V
+    const float *W, *V, *scale, *colsum;
+    float* H;                   // updated in place
+    long sW, sH, sV, sVec;      // per-file strides (floats)
+    int lda, ldb, ldv;          // row pitches of W, H, V
     int M, N, Kd, batch;
     float alpha, eps;
     int tiles_n, xc;            // filled in by the launcher

@@ -618,260 +618,215 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream) {
 
 // ---- K1 and K2 of one KL-NMF iteration in ONE launch, for short dictionaries (round 4) ----------------------------------------------
 //   R = V / (W . (s*H))   then   H = (s*H) * (W^T . R) / (colsum W + alpha + eps)            (gccNMFFunctions.py:76)
-// At K = 128 (the reference driver's default, runGCCNMF.py:41) the two throughput launches are bound by what they move, not by the matrix
-// cores: K1 writes R (2.7 MB per file) only for K2 to read it back, and both are 8 k-tiles of main loop against a 12 us epilogue
-// (64 files: 134 + 95 us against an MFMA floor of 2 x 66).  One row tile covers all F - 1 = 512 bins, so a workgroup (512 x 64, four
-// waves of 128 x 64 like the throughput tile) holds ALL of R for its 64 columns in its accumulators when K1 ends -- exactly what W^T . R
-// needs for those columns.  The second product therefore runs in the same workgroup, and R never leaves the registers:
-//   * v_mfma_f32_32x32x2_f32 leaves D[row (r&3) + 8 (r>>2) + 4 (lane>>5)][column lane&31] in register r.  Read as a B operand
-//     (B[k = lane>>5][j = lane&31]) register r IS a valid pair of reduction rows (f, f + 4) for the same 32 columns: the accumulators of
-//     K1 feed the MFMAs of K2 as they are, no LDS, no shuffle, no copy;
-//   * the A operand of that step is W [f][atom block] (32 consecutive atoms per lane half, 128 contiguous bytes per row);
-//   * each wave reduces over its own 128 rows, so the four waves' partial 32 x 64 atom blocks meet in LDS (wave order: deterministic),
-//     where the tail bin (a rank-1 term), the lazy scale and the denominator are applied and H is rewritten in place.
-// K1 itself is LDS-free as well: row-major W [f][k] IS the A operand when the k index a lane half owns is 4 consecutive atoms (one
-// 16-byte load per lane and 32 rows: MFMA step s of a chunk of 8 atoms multiplies atoms (k0 + s, k0 + 4 + s)), H rows come one float per
-// lane, the lazy scale sits on the A values.  The order of the sum over k is a property of this kernel (fixed, the same for every file and
-// batch size).  Requirements: one row tile (M <= 512, M % 128 == 0, bin M = the VALU tail), Kd <= 256, lda % 4 == 0.
+// K2 reduces over ALL bins of a file, so here a workgroup owns a COLUMN tile (64 frames) and walks the bins in chunks of 64 -- the mirror
+// image of the slab kernel below, with the roles of W and H exchanged:
+//   * the tile's scaled H (128 atoms x 64 frames) stays in registers for the whole launch: lane (frame n, half hh) keeps
+//     s[k] H[k][n] for its 64 atoms, laid out as the MFMA's B operand (64 VGPRs);
+//   * a chunk of W [64 bins][128 atoms] goes through LDS once (double-buffered, register-staged in two halves under the matrix work, one
+//     barrier per chunk) and is the operand of BOTH products: A of  D[f][n] = sum_k W[f][k] (sH)[k][n]  (a lane reads one float of its bin's
+//     row) and B of the transposed second product  numer^T[n][k] += sum_f R[f][n] W[f][k]  (a lane reads one float of atom column k);
+//   * register r of D holds bin (r&3) + 8 (r>>2) + 4 (lane>>5) for frame lane&31 -- read as an A operand (A[i = n][kk = lane>>5]) that IS
+//     a pair of reduction rows (bins f, f + 4): after the divide the accumulator registers feed the second product as they are;
+//   * numer^T (32 frames x 128 atoms per wave, 64 VGPRs) accumulates over all chunks; the two waves that share a frame half (bin groups
+//     fg = 0 / 1 of every chunk) meet in LDS at the end (fixed order), where the tail bin's rank-1 term, the pending scale and the
+//     denominator are applied and H is rewritten in place.  R never exists.
+// LDS image of a chunk: row pitch 129 floats (odd: the 32 bins of a first-product read hit 32 banks) and the rows permuted -- bin
+// b5 b4 b3 b2 b1 b0 sits in row b2 b5 b4 b3 b1 b0 -- so that (i) the 32 bins of a wave keep one value of row bit 4 (its lane half hh reads
+// 16 atoms further: the other 32 banks) and (ii) the bin pair (f, f + 4) of a second-product read is 32 rows = 32 banks apart.
+// Four waves: (bin group fg, frame half nh).  Requirements: M = F - 1 a multiple of 64 (bin M rides on the VALU), Kd <= 128.
 __device__ __forceinline__ float direct_div_fast(float v, float d) {      // v / d: v_rcp_f32 + one Newton step through the exact residual
     const float r = __builtin_amdgcn_rcpf(d);
     const float q = v * r;
     return fmaf(fmaf(-d, q, v), r, q);
 }
 
-template <int NBUF>
+template <int KB>
 __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs p) {
-    constexpr int BN = 64, RW = 128, CK = 8, RP = 68;          // chunk = 8 atoms = 4 MFMA steps of 2; RP: pitch of a partial atom block
-    __shared__ __attribute__((aligned(16))) float s_red[2][4][32][RP];      // partial atom blocks of the four waves, double-buffered
-    __shared__ float s_tailp[4][BN];                            // tail bin: partial dot products
-    __shared__ float s_rtail[BN];                               // R[tail bin][col]
+    constexpr int PW = 129, NT = 16 * KB, NK = 32 * KB;          // LDS pitch | MFMA steps of the first product | padded atoms
+    __shared__ float Ws[2][64][PW];
+    __shared__ float s_wm[NK], s_r[64];
     const int tiles = p.tiles_n;
-    int file = blockIdx.x / tiles, tn = blockIdx.x - file * tiles;
+    int idx = blockIdx.x;
     if (p.xc) {          // XCD x owns a contiguous eighth of the file-major tile list (blocks b, b + 8, ... run on XCD b % 8)
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, idx = xcd * p.xc + slot;
+        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
         if (idx >= p.batch * tiles) return;
-        file = idx / tiles;
-        tn = idx - file * tiles;
     }
-    file = __builtin_amdgcn_readfirstlane(file);
-    tn = __builtin_amdgcn_readfirstlane(tn);
-    const int col0 = tn * BN;
+    const int file = __builtin_amdgcn_readfirstlane(idx / tiles);
+    const int tn = __builtin_amdgcn_readfirstlane(idx - file * tiles);
+    const int col0 = tn * 64;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row_w = wave * RW;
-    const bool wave_active = row_w < p.M;
-    if (p.trace && tid == 0) {      // per-workgroup timeline (gccnmf_debug_set_trace, scripts/ktrace_fused.py)
+    const int fg = wave & 1, nh = wave >> 1;
+    const float* __restrict__ W = p.W + file * p.sW;            // [M + 1][lda]
+    float* __restrict__ H = p.H + file * p.sH;                  // [Kd][ldb], updated in place
+    const float* __restrict__ V = p.V + file * p.sV;
+    const float* __restrict__ sc = p.scale + file * p.sVec;
+    const int nchunks = p.M >> 6;
+    const int n = col0 + 32 * nh + l31;                          // this lane's frame
+    if (p.trace && tid == 0) {
         p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
         p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
     }
-    const float* __restrict__ Wt = p.Wt + file * p.sWt;         // [Kd][ldwt]  (k-major copy: the A operand of K1)
-    const float* __restrict__ W = p.W + file * p.sW;            // [M + 1][lda]
-    const float* __restrict__ H = p.H + file * p.sH;            // [Kd][ldb]
-    const float* __restrict__ sc = p.scale + file * p.sVec;     // the pending H row scale (always present on this path)
-    const int nchunks = (p.Kd + CK - 1) / CK;
-    const unsigned chunkA = 4u * CK * (unsigned)p.ldwt, chunkB = 4u * CK * (unsigned)p.ldb;
-    const __amdgpu_buffer_rsrc_t rA = direct_rsrc(Wt, (unsigned)nchunks * chunkA);
+    // staging: the chunk is 64 rows x 8 KB float4; thread tid moves float4 q = tid + 256 i (row q / (8 KB), atoms 4 (q % (8 KB)) ..), i < 2 KB,
+    // in two parts of KB float4 each; row (bin) b goes to LDS row slot(b)
     const __amdgpu_buffer_rsrc_t rW = direct_rsrc(W, 4u * (unsigned)(p.M + 1) * (unsigned)p.lda);
-    const __amdgpu_buffer_rsrc_t rB = direct_rsrc(H, (unsigned)nchunks * chunkB);
-    const __amdgpu_buffer_rsrc_t rS = direct_rsrc(sc, 4u * (unsigned)p.Kd);           // atoms >= Kd read as scale 0
-    unsigned offA[4], offB0[4], offB1[4];
+    auto stage_load = [&](df32x4 (&r)[KB], int chunk, int part) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {                               // MFMA step s of a chunk multiplies atoms (k0 + 2 s, k0 + 2 s + 1)
-        offA[s] = 4u * (unsigned)((2 * s + hh) * p.ldwt + min(row_w + 4 * l31, p.ldwt - 4));
-        offB0[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + l31, p.ldb - 1));
-        offB1[s] = 4u * (unsigned)((2 * s + hh) * p.ldb + min(col0 + 32 + l31, p.ldb - 1));
-    }
-    // ---- K1: acc[m][n][r] = (W . (s*H))[row_w + 4 ((r&3) + 8 (r>>2) + 4 hh) + m][col0 + 32 n + l31]      (interleaved row map: one
-    // 16-byte load of Wt covers the wave's four row blocks)
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    struct Frag {
-        df32x4 a[4];
-        float b0[4], b1[4], s[4];
-    };
-    auto load = [&](Frag& f, int ch) {
-        const unsigned chu = (unsigned)__builtin_amdgcn_readfirstlane(min(ch, nchunks - 1));
-        const unsigned sa = chu * chunkA, sb = chu * chunkB;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f.a[s] = DLoad<4>::ld(rA, offA[s], sa);
-            f.b0[s] = DLoad<1>::ld(rB, offB0[s], sb);
-            f.b1[s] = DLoad<1>::ld(rB, offB1[s], sb);
-            f.s[s] = DLoad<1>::ld(rS, 4u * (unsigned)(2 * s + hh), 4u * CK * chu);
+        for (int i = 0; i < KB; ++i) {
+            const int q = tid + 256 * (part * KB + i), row = q / (8 * KB), c4 = q - row * (8 * KB);
+            r[i] = DLoad<4>::ld(rW, 4u * (unsigned)(row * p.lda + 4 * c4), 4u * (unsigned)(64 * chunk * p.lda));
         }
     };
-    auto compute = [&](const Frag& f) {
+    auto stage_store = [&](const df32x4 (&r)[KB], int buf, int part) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float av = f.a[s][m] * f.s[s];               // the lazy H row scale, on the wave's own A values
-                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b0[s], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f.b1[s], acc[m][1], 0, 0, 0);
-            }
+        for (int i = 0; i < KB; ++i) {
+            const int q = tid + 256 * (part * KB + i), row = q / (8 * KB), c4 = q - row * (8 * KB);
+            const int slot = (row & 3) | (((row >> 3) & 3) << 2) | ((row >> 5) << 4) | (((row >> 2) & 1) << 5);
+            float* dst = &Ws[buf][slot][4 * c4];
+            dst[0] = r[i].x; dst[1] = r[i].y; dst[2] = r[i].z; dst[3] = r[i].w;
+        }
     };
-    if (wave_active) {
-        Frag f[NBUF];
+    df32x4 h0[KB], h1[KB];
+    stage_load(h0, 0, 0);
+    stage_load(h1, 0, 1);
+    if (tid < NK) s_wm[tid] = tid < p.Kd ? W[(long)p.M * p.lda + tid] : 0.f;
+    // the scaled H tile, resident: hr[t] = s[k] H[k][n], k = (t & 15) + 16 hh + 32 (t >> 4)   (MFMA step t multiplies atoms (k, k + 16))
+    float hr[NT];
+    {
+        const __amdgpu_buffer_rsrc_t rH = direct_rsrc(H, 4u * (unsigned)p.Kd * (unsigned)p.ldb);      // atoms >= Kd read as zero
+        const __amdgpu_buffer_rsrc_t rS = direct_rsrc(sc, 4u * (unsigned)p.Kd);
+        const unsigned ho = 4u * (unsigned)(16 * hh * p.ldb + min(n, p.ldb - 1));
 #pragma unroll
-        for (int j = 0; j < NBUF - 1; ++j) load(f[j], j);
-        int it = 0;
-        for (; it + NBUF <= nchunks; it += NBUF) {
+        for (int t = 0; t < NT; ++t) hr[t] = DLoad<1>::ld(rH, ho, 4u * (unsigned)(((t & 15) + 32 * (t >> 4)) * p.ldb));
 #pragma unroll
-            for (int j = 0; j < NBUF; ++j) {
+        for (int t = 0; t < NT; ++t) hr[t] *= DLoad<1>::ld(rS, 64u * (unsigned)hh, 4u * (unsigned)((t & 15) + 32 * (t >> 4)));
+    }
+    stage_store(h0, 0, 0);
+    stage_store(h1, 0, 1);
+    __syncthreads();
+    // tail bin: r[n] = V[M][n] / sum_k W[M][k] (sH)[k][n]   (each lane half sums its atoms, the halves meet by a shuffle)
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t = fmaf(s_wm[(i & 15) + 16 * hh + 32 * (i >> 4)], hr[i], t);
+        t += __shfl_xor(t, 32);
+        if (fg == 0 && hh == 0) s_r[32 * nh + l31] = n < p.N ? V[(long)p.M * p.ldv + n] / t : 0.f;
+    }
+    f32x16 nt[KB];                                               // numer^T[32 nh + rows][32 ab + lane&31], partial over this wave's bins
+#pragma unroll
+    for (int ab = 0; ab < KB; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nt[ab][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(V, 4u * (unsigned)(p.M + 1) * (unsigned)p.ldv);
+    const unsigned vo = 4u * (unsigned)(4 * hh * p.ldv + min(n, p.ldv - 1));
+    const int aslot = (l31 & 3) | (((l31 >> 3) & 3) << 2) | (fg << 4) | (((l31 >> 2) & 1) << 5);      // LDS row of bin 32 fg + l31
+    const float* arow0 = &Ws[0][aslot][16 * hh];
+    const float* brow0 = &Ws[0][16 * fg + 32 * hh][l31];          // second product: bin (r, hh) of the wave's group sits in row r + 16 fg + 32 hh
+    float av[8], bv[KB];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) av[t] = arow0[t];
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nchunks;
+        const float* arow = arow0 + cur * 64 * PW;
+        const float* brow = brow0 + cur * 64 * PW;
+        // The chunk's instruction order below IS the schedule (scheduling barriers between the small groups keep it), as in the slab kernel.
+        __builtin_amdgcn_s_setprio(2);                          // the first product is ONE dependent MFMA chain
+        if (more) stage_load(h0, c + 1, 0);
+        float v[16];                                            // V is read once, straight from HBM: requested a whole first product ahead
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = DLoad<1>::ld(rV, vo, 4u * (unsigned)((64 * c + 32 * fg + (r & 3) + 8 * (r >> 2)) * p.ldv));
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t == NT / 2) {
                 __builtin_amdgcn_sched_barrier(0);
-                load(f[(j + NBUF - 1) % NBUF], it + j + NBUF - 1);
-                compute(f[j]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (more) {
+                    stage_store(h0, cur ^ 1, 0);
+                    stage_load(h0, c + 1, 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 7], hr[t], d, 0, 0, 0);
+            if (t + 8 < NT) av[t & 7] = arow[((t + 8) & 15) + 32 * ((t + 8) >> 4)];
+            if (t >= NT - KB) bv[t - (NT - KB)] = brow[32 * (t - (NT - KB))];          // second product, bin pair r = 0: atom blocks 0 .. KB - 1
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        // R in place (0 beyond the last frame); bins are rows of d: (r&3) + 8 (r>>2) + 4 hh
 #pragma unroll
-        for (int j = 0; j < NBUF - 1; ++j)
-            if (it + j < nchunks) compute(f[j]);
-    }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();      // K1 main loop done (wave 0)
-    // ---- the tail bin (row M of W, on the VALU): 4 thread groups x Kd / 4 atoms each, then R[M][col] = V[M][col] / sum
-    {
-        const int c = tid & 63, q = tid >> 6;
-        const int col = min(col0 + c, p.ldb - 1);
-        const int per = (p.Kd + 3) >> 2, k0 = q * per, k1 = min(k0 + per, p.Kd);
-        const float* __restrict__ wt = W + (long)p.M * p.lda;
-        float t = 0.f;
-        for (int kb = k0; kb < k1; kb += 8) {                  // 8 independent loads in flight; atoms >= k1 contribute w = 0
-            float w[8], h[8];
+        for (int r = 0; r < 16; ++r) d[r] = n < p.N ? direct_div_fast(v[r], d[r]) : 0.f;
+        // second product (transposed): numer^T[n][32 ab + j] += sum_f R[f][n] W[f][32 ab + j]
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = min(kb + i, p.Kd - 1);
-                const float wv = wt[k] * sc[k];
-                w[i] = kb + i < k1 ? wv : 0.f;
-                h[i] = H[(long)k * p.ldb + col];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t = fmaf(w[i], h[i], t);
-        }
-        s_tailp[q][c] = t;
-    }
-    __syncthreads();
-    if (tid < BN) {
-        const float t = (s_tailp[0][tid] + s_tailp[1][tid]) + (s_tailp[2][tid] + s_tailp[3][tid]);
-        const int col = col0 + tid;
-        s_rtail[tid] = col < p.N ? p.V[file * p.sV + (long)p.M * p.ldv + col] / t : 0.f;
-    }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();      // tail bin done
-    // ---- R in place: acc = V / acc on the valid columns, 0 elsewhere (R is a reduction operand from here on).  Rows are addressed as a
-    // wave-uniform scalar offset (row_w + m + 4 ((r&3) + 8 (r>>2))) * pitch plus ONE per-lane offset (the lane half's 16 rows and the column)
-    const bool oka = col0 + l31 < p.N, okb = col0 + 32 + l31 < p.N;
-    const __amdgpu_buffer_rsrc_t rV = direct_rsrc(p.V + file * p.sV, 4u * (unsigned)(p.M + 1) * (unsigned)p.ldv);
-    const unsigned voVa = 4u * (unsigned)(16 * hh * p.ldv + min(col0 + l31, p.ldv - 1));
-    const unsigned voVb = 4u * (unsigned)(16 * hh * p.ldv + min(col0 + 32 + l31, p.ldv - 1));
-    const unsigned voW = 4u * (unsigned)(16 * hh * p.lda + l31);
-    if (wave_active) {
-        float xa[2][16], xb[2][16];                         // the V tile of row block m + 1 is in flight while block m is divided
-        auto loadv = [&](int m, float* a, float* b) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned so = 4u * (unsigned)((row_w + m + 4 * ((r & 3) + 8 * (r >> 2))) * p.ldv);
-                a[r] = DLoad<1>::ld(rV, voVa, so);
-                b[r] = DLoad<1>::ld(rV, voVb, so);
-            }
-        };
-        loadv(0, xa[0], xb[0]);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (m + 1 < 4) loadv(m + 1, xa[(m + 1) & 1], xb[(m + 1) & 1]);
+        for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[m][0][r] = oka ? direct_div_fast(xa[m & 1][r], acc[m][0][r]) : 0.f;
-                acc[m][1][r] = okb ? direct_div_fast(xb[m & 1][r], acc[m][1][r]) : 0.f;
+            for (int ab = 0; ab < KB; ++ab) {
+                nt[ab] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[r], bv[ab], nt[ab], 0, 0, 0);
+                if (r + 1 < 16) bv[ab] = brow[(r + 1) * PW + 32 * ab];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();      // R in the accumulators
-    // ---- K2: per block of 32 atoms, partial (W^T . R) over this wave's 128 rows with the accumulators of K1 as B operands
-    const int nab = (p.Kd + 31) >> 5;
-    const int al = tid >> 3, cg = 8 * (tid & 7);                  // finishing thread: atom al of the block, columns cg .. cg + 7
-    float* Hout = p.Hout + file * p.sH;
-    float wa[2][16];                                              // W fragments: (atom block, row block) step i + 1 in flight under step i
-    auto loadw = [&](int ab, int m, float* a) {
-        const int abc = min(ab, nab - 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = DLoad<1>::ld(rW, voW, 4u * (unsigned)((row_w + m + 4 * ((r & 3) + 8 * (r >> 2))) * p.lda + 32 * abc));
-    };
-    if (wave_active) loadw(0, 0, wa[0]);
-    for (int ab = 0; ab < nab; ++ab) {
-        f32x16 u0, u1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u0[r] = u1[r] = 0.f;
-        if (wave_active) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (m + 1 < 4) loadw(ab, m + 1, wa[(m + 1) & 1]);
-                else loadw(ab + 1, 0, wa[0]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m & 1][r], acc[m][0][r], u0, 0, 0, 0);
-                    u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[m & 1][r], acc[m][1][r], u1, 0, 0, 0);
-                }
-            }
+        if (more) {
+            stage_store(h0, cur ^ 1, 1);
             __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) av[t] = arow0[(cur ^ 1) * 64 * PW + t];
         }
-        // what the finishing step needs from global memory is requested before the exchange
-        const int atom = 32 * ab + al;
-        const int arow = min(atom, p.Kd - 1);
-        const df32x4 h0 = *(const df32x4*)(Hout + (long)arow * p.ldb + col0 + cg), h1 = *(const df32x4*)(Hout + (long)arow * p.ldb + col0 + cg + 4);
-        const float s_at = sc[arow];
-        const float rd = 1.0f / (p.colsum[file * p.sVec + arow] + p.alpha + p.eps);
-        const float wt_at = W[(long)p.M * p.lda + arow];
-        float (*red)[32][RP] = s_red[ab & 1];
+    }
+    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    // The two bin groups of a frame half meet in LDS (the W chunks are done): fg = 1 hands its part over, fg = 0 adds it to its own, applies
+    // the tail bin's rank-1 term, the pending scale and the denominator, and rewrites H.  What that step needs from global memory (the old H
+    // values: four consecutive frames per lane and step) is requested before the exchange.
+    // nt[ab][r]: frame col0 + 32 nh + (r&3) + 8 (r>>2) + 4 hh, atom 32 ab + l31.
+    float* red = &Ws[0][0][0];                                   // [nh][ab][r][lane]
+    df32x4 h4[KB][4];
+    float s_at[KB], wm_at[KB], rd[KB];
+    if (fg == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int a_l = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            red[wave][a_l][l31] = u0[r];
-            red[wave][a_l][32 + l31] = u1[r];
+        for (int ab = 0; ab < KB; ++ab) {
+            const int arow_ = min(32 * ab + l31, p.Kd - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h4[ab][j] = *(const df32x4*)(H + (long)arow_ * p.ldb + col0 + 32 * nh + 8 * j + 4 * hh);
+            s_at[ab] = sc[arow_];
+            wm_at[ab] = W[(long)p.M * p.lda + arow_];
+            rd[ab] = 1.0f / (p.colsum[file * p.sVec + arow_] + p.alpha + p.eps);
         }
-        __syncthreads();
-        if (atom < p.Kd) {
-            df32x4 o[2];
+    }
+    __syncthreads();
+    if (fg == 1) {
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                df32x4 u = *(const df32x4*)&red[0][al][cg + 4 * v];
+        for (int ab = 0; ab < KB; ++ab)
 #pragma unroll
-                for (int w = 1; w < 4; ++w) u += *(const df32x4*)&red[w][al][cg + 4 * v];
-                const df32x4 rt = *(const df32x4*)&s_rtail[cg + 4 * v];
-                const df32x4 h = v ? h1 : h0;
-                o[v] = df32x4{(h.x * s_at) * (fmaf(wt_at, rt.x, u.x) * rd), (h.y * s_at) * (fmaf(wt_at, rt.y, u.y) * rd),
-                              (h.z * s_at) * (fmaf(wt_at, rt.z, u.z) * rd), (h.w * s_at) * (fmaf(wt_at, rt.w, u.w) * rd)};
-                const int c = col0 + cg + 4 * v;                 // columns >= N: H is zero there and stays zero
-                o[v].x = c < p.N ? o[v].x : 0.f;
-                o[v].y = c + 1 < p.N ? o[v].y : 0.f;
-                o[v].z = c + 2 < p.N ? o[v].z : 0.f;
-                o[v].w = c + 3 < p.N ? o[v].w : 0.f;
-                if (c < p.N) *(df32x4*)(Hout + (long)atom * p.ldb + c) = o[v];
+            for (int r = 0; r < 16; ++r) red[((nh * KB + ab) * 16 + r) * 64 + lane] = nt[ab][r];
+    }
+    __syncthreads();
+    if (fg == 0) {
+#pragma unroll
+        for (int ab = 0; ab < KB; ++ab) {
+            const int atom = 32 * ab + l31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nl = 32 * nh + 8 * j + 4 * hh, nn = col0 + nl;          // first of the four frames
+                df32x4 out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = nt[ab][4 * j + q] + red[((nh * KB + ab) * 16 + 4 * j + q) * 64 + lane];
+                    out[q] = nn + q < p.N ? (h4[ab][j][q] * s_at[ab]) * (fmaf(wm_at[ab], s_r[nl + q], u) * rd[ab]) : 0.f;
+                }
+                if (atom < p.Kd && nn < p.N) *(df32x4*)(H + (long)atom * p.ldb + nn) = out;
             }
         }
-        // (the other buffer of s_red is free again: its readers passed this block's barrier after finishing the block before)
     }
     if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream) {
-    if (!a.Wt || !a.W || !a.H || !a.Hout || !a.V || !a.colsum || !a.scale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
-    if (a.M < 128 || a.M > 512 || (a.M & 127) || a.Kd < 1 || a.Kd > 256 || (a.lda & 3) || (a.ldb & 3) || (a.ldwt & 3))
-        return GCCNMF_ERR_UNSUPPORTED;
+    if (!a.W || !a.H || !a.V || !a.colsum || !a.scale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
+    if (a.M < 64 || a.M > 512 || (a.M & 63) || a.Kd < 1 || a.Kd > 128 || (a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_UNSUPPORTED;
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     int grid = a.batch * a.tiles_n;
     a.xc = 0;
@@ -880,8 +835,11 @@ int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream) {
         grid = 8 * a.xc;
     }
     a.trace = (gccnmf_trace_buf && grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;
-    if (gccnmf_tune_direct_depth == 3) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(gccnmf_wh_updh_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    const int kb = gccnmf_ceil_div(a.Kd, 32);
+    if (kb == 1) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<1>, dim3(grid), dim3(256), 0, stream, a);
+    else if (kb == 2) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
+    else if (kb == 3) hipLaunchKernelGGL(gccnmf_wh_updh_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gccnmf_wh_updh_kernel<4>, dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

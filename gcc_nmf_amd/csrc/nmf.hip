@@ -35,7 +35,8 @@ int gccnmf_tune_fft_r16 = 1;       // key 15: 1 (default) = the offline STFT / i
 int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
 int gccnmf_tune_fused_k34 = 1;     // key 17: short dictionaries (K <= 128) run K3 and K4a as ONE launch of 64-bin slabs, R never written (direct.hip):
                                    // 0 never, 1 (default) when its whole rounds of 512 workgroups beat the two launches, 2 whenever the shape allows
-int gccnmf_tune_fused_k12 = 0;     // key 16: 1 = short dictionaries (K <= 256, one row tile) run K1 and K2 as ONE launch, R kept in registers (direct.hip)
+int gccnmf_tune_fused_k12 = 1;     // key 16: short dictionaries (K <= 128) run K1 and K2 as ONE launch of column tiles with H resident, R never written (direct.hip):
+                                   // 0 never, 1 (default) when its rounds of 512 workgroups beat the two launches, 2 whenever the shape allows
 int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
@@ -88,7 +89,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_short_updh = value;
         return GCCNMF_OK;
     }
-    if (key == 16 && (value == 0 || value == 1)) {
+    if (key == 16 && value >= 0 && value <= 2) {
         gccnmf_tune_fused_k12 = value;
         return GCCNMF_OK;
     }
@@ -726,21 +727,26 @@ static int direct_rht(const NmfGeom& g, const DirectBufs& d, const float* R, flo
     return gccnmf_direct_launch(a, DEPI_STORE, gccnmf_tune_direct_tile, s);
 }
 
-// Short dictionaries (K <= 256 -- the reference driver's K = 128): K1 and K2 as ONE launch (gccnmf_wh_updh_kernel), R never written.
-// Its first product reads W k-major (Wt [batch][Kp][Fp], written by the W update next to W): one more scratch matrix per file.
-static bool fused_shape(const NmfGeom& g, int batch) {
-    return batch > 1 && g.tail && g.Fm >= 128 && g.Fm <= 512 && (g.Fm % 128) == 0 && g.K <= 256;
+// Short dictionaries (K <= 128 -- the reference driver's K = 128): K1 and K2 as ONE launch (gccnmf_wh_updh_kernel: a workgroup per
+// 64-frame column tile with its scaled H resident in registers, W in 64-bin chunks through LDS), R never written.
+// Measured at K = 128, N = 1244 (profiles/r04w_fused_k12_sweep.txt; files: fused / two launches, us): 20: 82 / 92, 25: 86 / 109, 26: 127 / 123,
+// 40: 153 / 186, 50: 160 / 189, 64: 208 / 240, 96: 312 / 333, 128: 379 / 431; K = 64, 64 files: 116 / 195.  A full round of 512 workgroups
+// (two per CU) takes 78 us, a last round of at most 256 (one per CU) 45, a larger one 76; the two launches 25 + 0.17 us per column tile.
+// Both scale alike with K, so the choice is made in those units.  (flags bit 2: another file group of the same size runs beside this one.)
+static bool fused_wh_updh(const NmfGeom& g, int batch, int flags) {
+    if (!gccnmf_tune_fused_k12 || gccnmf_tune_tile_policy != 0 || direct_path(g, batch) || batch < 2 || !g.tail || g.Fm < 64 || g.Fm > 512 ||
+        (g.Fm % 64) != 0 || g.K > 128)
+        return false;
+    if (gccnmf_tune_fused_k12 == 2) return true;
+    const long wgs = (long)batch * gccnmf_ceil_div(g.N, 64) * ((flags & 4) ? 2 : 1), rem = wgs % 512;
+    const long fused = 780 * (wgs / 512) + (rem == 0 ? 0 : rem <= 256 ? 450 : 760), two = 250 + 17 * wgs / 10;      // tenths of a microsecond
+    return fused < two;
 }
-static long fused_floats(const NmfGeom& g, int batch) { return fused_shape(g, batch) ? (long)batch * g.sU : 0; }
-static bool fused_wh_updh(const NmfGeom& g, int batch) {
-    return gccnmf_tune_fused_k12 && gccnmf_tune_tile_policy == 0 && !direct_path(g, batch) && fused_shape(g, batch);
-}
-static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, const float* Wt, float* H, const float* hscale, const float* colsumW,
-                          float alpha, float eps, int batch, hipStream_t s) {
+static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, float* H, const float* hscale, const float* colsumW, float alpha,
+                          float eps, int batch, hipStream_t s) {
     WhUpdhArgs a = {};
-    a.Wt = Wt; a.sWt = g.sU; a.ldwt = g.Fp;
     a.W = W; a.sW = g.sW; a.lda = g.Kp;
-    a.H = H; a.Hout = H; a.sH = g.sH; a.ldb = g.ld;
+    a.H = H; a.sH = g.sH; a.ldb = g.ld;
     a.V = V; a.sV = g.sV; a.ldv = g.ld;
     a.scale = hscale; a.colsum = colsumW; a.sVec = g.Kp;
     a.M = g.Fm; a.N = g.N; a.Kd = g.K; a.batch = batch;
@@ -777,13 +783,12 @@ extern "C" {
 // R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
 // GCCNMF_SPLITS x max(Fp*Np, Fp*Kp) (W.H parts and R.H^T parts use the same memory at different stages) + GCCNMF_SPLITS x Kp
 // | (batch <= GCCNMF_DIRECT_MAX_BATCH) the transposed copies of the direct path: Wt [batch][Kp][Fp], Ht [batch][Np][Kp], Rt [batch][Np][Fp]
-// | (short dictionaries, fused_shape) Wt [batch][Kp][Fp] of the fused K1 + K2 launch
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
     long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
     if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
-    return n + direct_floats(g, batch) + fused_floats(g, batch);      // Wt | Ht | Rt of the direct path (a handful of files at most) | Wt of the fused short-dictionary launch
+    return n + direct_floats(g, batch);                       // Wt | Ht | Rt of the direct path (a handful of files at most)
 }
 
 // One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
@@ -798,8 +803,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
     float* direct_base = batch == 1 ? rowsum_parts + GCCNMF_SPLITS * (long)g.Kp : parts;
-    float* fusedWt = direct_base + direct_floats(g, batch);                       // fused_shape only
-    const bool fused12 = fused_wh_updh(g, batch), fused34 = fused_whdiv_rht(g, batch, flags);
+    const bool fused12 = fused_wh_updh(g, batch, flags), fused34 = fused_whdiv_rht(g, batch, flags);
     if (direct_path(g, batch)) {
         const DirectBufs d = direct_bufs(g, direct_base, batch);
         switch (stage) {
@@ -834,14 +838,9 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             // R's padding (rows >= F, columns >= N) must be zero: it is a reduction operand of K2 and K4a.
             if (hipMemsetAsync(R, 0, sizeof(float) * batch * g.sV, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
             hipLaunchKernelGGL(nmf_prepare_kernel, dim3(vec_grid), dim3(256), 0, s, W, colsumW, hscale, g.F, g.Fp, g.Kp);
-            if (fused12) {
-                GCCNMF_CHECK_LAUNCH();
-                if (hipMemsetAsync(fusedWt, 0, sizeof(float) * fused_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
-                return gccnmf_transpose_launch(W, g.sW, g.Kp, fusedWt, g.sU, g.Fp, g.F, g.Kp, batch, s);
-            }
             break;
         case 1:
-            if (fused12) return launch_wh_updh(g, V, W, fusedWt, H, hscale, colsumW, alpha, eps, batch, s);                // K1 + K2
+            if (fused12) return launch_wh_updh(g, V, W, H, hscale, colsumW, alpha, eps, batch, s);                         // K1 + K2
             if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
         case 2:
@@ -860,10 +859,8 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             if (split_rht)
                 return launch_update_w(W, parts, rowsum_parts, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch,
                                        s, gccnmf_tune_rht_splits, g.sU, (long)g.Kp);
-            if (can_fuse_w_update(g, batch) && !(flags & 2) && !fused34)           // done by stage 4's epilogue
-                return fused12 ? gccnmf_transpose_launch(W, g.sW, g.Kp, fusedWt, g.sU, g.Fp, g.F, g.Kp, batch, s) : GCCNMF_OK;
-            return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s, 1, 0, 0,
-                                   fused12 ? fusedWt : nullptr, g.sU, g.Fp);
+            if (can_fuse_w_update(g, batch) && !(flags & 2) && !fused34) return GCCNMF_OK;     // done by stage 4's epilogue
+            return launch_update_w(W, U, rowsumH, colsumW, hscale, g.F, g.Fp, g.K, g.Kp, g.sW, g.sU, (long)g.Kp, (long)g.Kp, batch, s);
         case 6:
             hipLaunchKernelGGL(nmf_scale_h_kernel, dim3(batch * g.K), dim3(256), 0, s, H, hscale, (long)g.Kp, g.K, g.sH, g.ld, g.Np);
             break;
@@ -878,7 +875,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     const NmfGeom g = make_geom(F, N, K);
-    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch) ? 2 : 0) | (fused_whdiv_rht(g, batch, flags) ? 4 : 0);
+    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht(g, batch, flags) ? 4 : 0);
 }
 
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,

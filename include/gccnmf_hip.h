@@ -62,10 +62,11 @@ int gccnmf_version(void);
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..16, default 4).
  * key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4).  key 14: 1 (default) = H updates of at most 128
  * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.
- * keys 16 / 17: short dictionaries (the reference driver's K = 128, runGCCNMF.py:41), F = 128 n + 1 <= 513.  key 17: K3 + K4a of an
- * iteration as ONE launch of 64-bin slabs that keep their W rows in registers and never write R (K <= 128; csrc/direct.hip): 0 never,
- * 1 (default) when its whole rounds of 512 workgroups beat the two launches (from about 50 files per round), 2 whenever the shape allows.
- * key 16: 1 = K1 + K2 as ONE launch with R kept in the accumulators (K <= 256; default 0: measured equal to the two launches).
+ * keys 16 / 17: short dictionaries (K <= 128: the reference driver's K = 128, runGCCNMF.py:41), F = 64 n + 1 <= 513 -- two launches of an
+ * iteration become one and R is never written (csrc/direct.hip).  key 16: K1 + K2 as ONE launch of 64-frame column tiles that keep their
+ * scaled H in registers and stream W through LDS.  key 17: K3 + K4a as ONE launch of 64-bin slabs that keep their W rows in registers and
+ * stream H through LDS.  Values: 0 never, 1 (default) when a cost model of whole rounds of 512 workgroups says it beats the two launches
+ * (from about 50 files per GPU at N = 1244), 2 whenever the shape allows.  gccnmf_klnmf_plan reports the choice.
  * Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
@@ -127,7 +128,7 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
                  int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
 
 /* Which launches gccnmf_klnmf uses for this problem under the current tuning: bit 0 = the direct latency kernels (a handful of files),
- * bit 1 = K1 + K2 as one launch (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17).  -1 on bad arguments.
+ * bit 1 = K1 + K2 as one launch of column tiles (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17).  -1 on bad arguments.
  * (Benchmarks and tests name the kernel they time by this; the result of gccnmf_klnmf does not depend on it beyond round-off.) */
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags);
 

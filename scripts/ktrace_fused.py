@@ -15,6 +15,7 @@ def main():
     ap.add_argument('--K', type=int, default=128)
     ap.add_argument('--files', type=int, default=64)
     ap.add_argument('--stage', type=int, default=1)
+    ap.add_argument('--slab', action='store_true', help='slab-style timeline slots (start | loop done | end) for the stage')
     a = ap.parse_args()
     import torch
     from gcc_nmf_amd import _hip
@@ -60,7 +61,7 @@ def main():
     cu = t[:, 4] >> 8
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
     print('stage %d: %d workgroups on %d CUs (max %d per CU); launch span %.1f us' % (a.stage, len(t), len(per_cu), per_cu.max(), us[:, 3].max()))
-    if a.stage == 3:                                            # slab kernel: start | tile loop done | end
+    if a.stage == 3 or a.slab:                                            # slab kernel: start | tile loop done | end
         for name, v in [('start            ', us[:, 0]), ('tile loop   t2-t0', us[:, 2] - us[:, 0]), ('finish      t3-t2', us[:, 3] - us[:, 2]), ('end              ', us[:, 3])]:
             print('   %s  min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f us' % ((name,) + tuple(np.percentile(v, [0, 10, 50, 90, 100]))))
         xcd = t[:, 4] >> 16

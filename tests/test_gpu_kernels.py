@@ -15,7 +15,7 @@ from oracle import gccnmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip('torch')
-FUSED_K12_DEFAULT = 0       # library defaults of tuning keys 16 and 17
+FUSED_K12_DEFAULT = 1       # library defaults of tuning keys 16 and 17 (1 = when the cost model says so; 2 = whenever the shape allows)
 FUSED_K34_DEFAULT = 1       # (1 = when the launch's whole rounds of 512 workgroups pay; 2 = whenever the shape allows)
 
 
@@ -457,8 +457,8 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
                                            (513, 330, 128, 13, 0.0), (513, 50, 96, 5, 0.1), (513, 37, 20, 8, 0.0), (129, 64, 32, 5, 0.0)])
 def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
     """Short dictionaries (the reference driver's K = 128: runGCCNMF.py:41): K1 + K2 of an iteration as ONE launch with R kept in the
-    accumulators (tuning key 16, K <= 256) and K3 + K4a as ONE launch of 64-bin slabs with their W rows in registers (key 17, K <= 128;
-    csrc/direct.hip) against the four-launch form and the oracle; the padding of W and H stays exactly zero; a file's bits do not
+    H resident in the registers of a column tile's workgroup (tuning key 16) and K3 + K4a as ONE launch of 64-bin slabs with their W
+    rows in registers (key 17; both K <= 128, csrc/direct.hip) against the four-launch form and the oracle; the padding of W and H stays exactly zero; a file's bits do not
     depend on the batch."""
     lib = hip.lib()
     from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
@@ -469,12 +469,12 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
     W0, H0 = klnmf_initial_factors(F, N, K)
     res = {}
     try:
-        for name, k16, k17, files in [('four-launch', 0, 0, list(range(B))), ('fused-12', 1, 0, list(range(B))), ('fused-34', 0, 2, list(range(B))),
-                                      ('fused', 1, 2, list(range(B))), ('fused-some', 1, 2, [B - 1, 0, 2, 1, 3])]:
+        for name, k16, k17, files in [('four-launch', 0, 0, list(range(B))), ('fused-12', 2, 0, list(range(B))), ('fused-34', 0, 2, list(range(B))),
+                                      ('fused', 2, 2, list(range(B))), ('fused-some', 2, 2, [B - 1, 0, 2, 1, 3])]:
             assert lib.gccnmf_set_tuning(16, k16) == 0 and lib.gccnmf_set_tuning(17, k17) == 0
             b = len(files)
             if F == 513:                                       # the library reports the launches it will use
-                assert lib.gccnmf_klnmf_plan(F, N, K, b, 0) == (2 if k16 else 0) | (4 if k17 and K <= 128 else 0), name
+                assert lib.gccnmf_klnmf_plan(F, N, K, b, 0) == ((2 if k16 else 0) | (4 if k17 else 0) if K <= 128 else 0), name
             Vd = padded(V[files], (b, g.Fp, g.Np), 'cuda')
             Wd = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
             Hd = padded(np.repeat(H0[None], b, 0), (b, g.Kp, g.Np), 'cuda')

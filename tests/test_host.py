@@ -45,10 +45,7 @@ def test_pitches_and_workspace_sizes():
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 64) == 64 * base                           # (a handful of files at most)
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + direct      # + the split-K partials of one file alone
     assert lib.gccnmf_klnmf_workspace_floats(513, 0, 1024, 1) == -1
-    # short dictionaries (K <= 256, F = 128 n + 1 <= 513) carry one more scratch matrix per file: the k-major copy of W for the fused K1 + K2 launch
-    base128 = 528 * 1280 + 528 * 128 + 3 * 128
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 128, 64) == 64 * (base128 + 128 * 528)
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 512, 64) == 64 * (528 * 1280 + 528 * 512 + 3 * 512)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 128, 64) == 64 * (528 * 1280 + 528 * 128 + 3 * 128)     # (the fused short-dictionary launches need no scratch)
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.gccnmf_klnmf(0, 0, 0, 0, 513, 1244, 1024, 1, 1, 0.0, 1e-16, 0, 0) == 1
     assert lib.gccnmf_stft_stereo(0, 0, 0, 1000, 256, 1, 1, 0, 0, 0, 0, 0, 0) == 1
@@ -80,7 +77,7 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
     assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 3) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
     assert lib.gccnmf_set_tuning(10, 2) == 1 and lib.gccnmf_set_tuning(11, 9) == 1 and lib.gccnmf_set_tuning(12, 17) == 1
-    assert lib.gccnmf_set_tuning(16, 2) == 1 and lib.gccnmf_set_tuning(17, 3) == 1 and lib.gccnmf_set_tuning(17, 1) == 0 and lib.gccnmf_set_tuning(16, 0) == 0
+    assert lib.gccnmf_set_tuning(16, 3) == 1 and lib.gccnmf_set_tuning(17, 3) == 1 and lib.gccnmf_set_tuning(17, 1) == 0 and lib.gccnmf_set_tuning(16, 1) == 0
     d = _hip.DirectGemm()
     assert lib.gccnmf_gemm_direct(None, 0, 0, None) == 1 and lib.gccnmf_gemm_direct(ctypes.byref(d), 0, 0, None) == 1        # null operands
     assert lib.gccnmf_rccl_comm_init(None, 2, 0, None) == 1 and lib.gccnmf_rccl_allreduce(None, None, 4, None) == 1
