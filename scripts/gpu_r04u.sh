@@ -16,10 +16,11 @@ echo "== bench"
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cut -c1-300 $OUT/bench.json; tail -3 $OUT/bench.err
 timeout 600 python bench.py --dictionary-size 128 --steps 5 --warmup 1 > $OUT/bench_K128.json 2> $OUT/bench_K128.err; echo "bench K128 exit $?"; cut -c1-200 $OUT/bench_K128.json
 timeout 600 python bench.py --dictionary-size 128 --hop 128 --steps 5 --warmup 1 > $OUT/bench_K128_hop128.json 2> $OUT/bench_K128_hop128.err; echo "bench K128 hop128 exit $?"; cut -c1-200 $OUT/bench_K128_hop128.json
-GCCNMF_TUNE=17=0 timeout 600 python bench.py --dictionary-size 128 --steps 5 --warmup 1 --skip-extras > $OUT/bench_K128_four_launches.json 2> /dev/null; echo "bench K128 (key 17 = 0) exit $?"; cut -c1-200 $OUT/bench_K128_four_launches.json
+GCCNMF_TUNE=16=0,17=0 timeout 600 python bench.py --dictionary-size 128 --steps 5 --warmup 1 --skip-extras > $OUT/bench_K128_four_launches.json 2> /dev/null; echo "bench K128 (keys 16, 17 = 0) exit $?"; cut -c1-200 $OUT/bench_K128_four_launches.json
 echo "== K = 128 stage times (kbench) and the slab launch's workgroup timeline"
 timeout 300 python scripts/kbench.py --K 128 --reps 10 > $OUT/kbench_K128.txt 2>&1; grep -E '^K[0-9].* fused|^K4b' $OUT/kbench_K128.txt
 timeout 300 python scripts/ktrace_fused.py --stage 3 > $OUT/ktrace_slab_K128.txt 2>&1; cat $OUT/ktrace_slab_K128.txt
+timeout 300 python scripts/ktrace_fused.py --stage 1 --slab > $OUT/ktrace_column_tiles_K128.txt 2>&1; cat $OUT/ktrace_column_tiles_K128.txt
 echo "== rocprofv3 kernel stats"
 prof() {  # name, command...
   local name=$1; shift
