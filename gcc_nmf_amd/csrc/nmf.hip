@@ -732,13 +732,18 @@ static int direct_rht(const NmfGeom& g, const DirectBufs& d, const float* R, flo
 // Measured at K = 128, N = 1244 (profiles/r04w_fused_k12_sweep.txt; files: fused / two launches, us): 20: 82 / 92, 25: 86 / 109, 26: 127 / 123,
 // 40: 153 / 186, 50: 160 / 189, 64: 208 / 240, 96: 312 / 333, 128: 379 / 431; K = 64, 64 files: 116 / 195.  A full round of 512 workgroups
 // (two per CU) takes 78 us, a last round of at most 256 (one per CU) 45, a larger one 76; the two launches 25 + 0.17 us per column tile.
-// Both scale alike with K, so the choice is made in those units.  (flags bit 2: another file group of the same size runs beside this one.)
+// Both scale alike with K, so the choice is made in those units.  (GCCNMF_FLAG_GROUPS: the file groups that run side by side are priced together.)
+// file groups that run this call side by side on separate streams (GCCNMF_FLAG_GROUPS): launch forms are chosen for all of them together
+static int concurrent_groups(int flags) {
+    const int n = (flags >> 8) & 255;
+    return (flags & 4) ? (n >= 2 ? n : 2) : 1;
+}
 static bool fused_wh_updh(const NmfGeom& g, int batch, int flags) {
     if (!gccnmf_tune_fused_k12 || gccnmf_tune_tile_policy != 0 || direct_path(g, batch) || batch < 2 || !g.tail || g.Fm < 64 || g.Fm > 512 ||
         (g.Fm % 64) != 0 || g.K > 128)
         return false;
     if (gccnmf_tune_fused_k12 == 2) return true;
-    const long wgs = (long)batch * gccnmf_ceil_div(g.N, 64) * ((flags & 4) ? 2 : 1), rem = wgs % 512;
+    const long wgs = (long)batch * gccnmf_ceil_div(g.N, 64) * concurrent_groups(flags), rem = wgs % 512;
     const long fused = 780 * (wgs / 512) + (rem == 0 ? 0 : rem <= 256 ? 450 : 760), two = 250 + 17 * wgs / 10;      // tenths of a microsecond
     return fused < two;
 }
@@ -758,13 +763,13 @@ static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, floa
 // Every slab workgroup walks ALL column tiles of its file, so the launch costs one "round" (two workgroups per CU, 512 at a time) however
 // few workgroups it holds: measured at K = 128, N = 1244 a round takes 184 us against 3.72 us per file for the two launches it replaces
 // (64 files: 184 against 238 us; 40 files: 184 against 149).  Both scale alike with K and N, so the choice is a ratio: the fused launch
-// runs when batch * slabs / 8 > 49.5 * rounds.  (flags bit 2: another file group of the same size runs beside this one and shares the round.)
+// runs when batch * slabs / 8 > 49.5 * rounds.  (GCCNMF_FLAG_GROUPS: the file groups that run side by side share the rounds.)
 static bool fused_whdiv_rht(const NmfGeom& g, int batch, int flags) {
     if (!gccnmf_tune_fused_k34 || gccnmf_tune_tile_policy != 0 || direct_path(g, batch) || batch < 2 || !g.tail || g.Fm < 64 || g.Fm > 512 ||
         (g.Fm % 64) != 0 || g.K > 128 || (g.Fm / 64) * 16 < 32 * gccnmf_ceil_div(g.K, 32))
         return false;
     if (gccnmf_tune_fused_k34 == 2) return true;
-    const long slabs = g.Fm / 64, wgs = (long)batch * slabs * ((flags & 4) ? 2 : 1), rounds = (wgs + 511) / 512;
+    const long slabs = g.Fm / 64, wgs = (long)batch * slabs * concurrent_groups(flags), rounds = (wgs + 511) / 512;
     return 8 * 495 * rounds < 10 * wgs;
 }
 static int launch_whdiv_rht(const NmfGeom& g, const float* V, const float* W, const float* H, float* U, float* rowsumH, int batch, hipStream_t s) {

@@ -217,11 +217,12 @@ class GCCNMFEngine(object):
         for i, st in enumerate(self.nmf_streams):
             st.wait_event(ready)
             b0 = i * per
-            # flag 4 (GCCNMF_FLAG_CONCURRENT_GROUPS): the groups' launches share the chip, so each keeps the throughput tile -- its
+            # GCCNMF_FLAG_GROUPS(n) = 4 | n << 8: the groups' launches share the chip, so launch forms are chosen for all groups together (a
+            # file's bits do not depend on the split) and each keeps the throughput tile -- its
             # partial last round overlaps the other group's kernels (all-half-height tiles, which win for a 32-file launch ALONE,
             # lose here: 152.4 k vs 155.4 k frames/s)
             _hip.check(self.lib.gccnmf_klnmf(_ptr(self.V[b0]), _ptr(self.W[b0]), _ptr(self.H[b0]), _ptr(self.ws_nmf[i * ws_per:]), g.F, g.N,
-                                             g.K, per, self.iters, self.alpha, self.eps, self.klnmf_flags | 4, st.cuda_stream), 'gccnmf_klnmf')
+                                             g.K, per, self.iters, self.alpha, self.eps, self.klnmf_flags | 4 | (self.nmf_groups << 8), st.cuda_stream), 'gccnmf_klnmf')
             done = torch.cuda.Event()
             done.record(st)
             main.wait_event(done)

@@ -40,6 +40,9 @@ extern "C" {
 #define GCCNMF_FLAG_UNFUSED_W_UPDATE 2   /* R.H^T and the W update/normalisation as two launches (always so when F-1 > 512) */
 #define GCCNMF_FLAG_CONCURRENT_GROUPS 4  /* another file group runs the same call on another stream: keep the throughput tile (a launch
                                           * that has the chip to itself may run its partial last round, or all of it, on half-height tiles) */
+#define GCCNMF_FLAG_GROUPS(n) (GCCNMF_FLAG_CONCURRENT_GROUPS | ((n) << 8))   /* ... n equal groups in all (bits 8-15; 0 = two): launch forms that
+                                          * are chosen by the size of a launch (tuning keys 16 / 17) are chosen for the groups together, so a
+                                          * file's result does not depend on how the batch was split */
 
 int gccnmf_version(void);
 
