@@ -84,6 +84,28 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_stft_dft(0, 0, 0, 1000, 250, 1, 1, 0, 0, 0, 0) == 1 and lib.gccnmf_dft_workspace_floats(1000, 0, 2) == -1
 
 
+def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
+    """gccnmf_klnmf_plan: which launches gccnmf_klnmf will use (no device needed).  Short dictionaries at batch scale take the fused
+    launches when whole rounds of 512 workgroups pay; file groups that run side by side (GCCNMF_FLAG_GROUPS) are planned together."""
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    plan = lib.gccnmf_klnmf_plan
+    assert plan(513, 1244, 1024, 1, 0) == 1 and plan(513, 1244, 1024, 4, 0) == 1 and plan(513, 1244, 1024, 64, 0) == 0     # direct path: up to 4 files
+    assert plan(513, 1244, 128, 64, 0) == 6 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
+    assert plan(513, 1244, 128, 96, 0) == 2 and plan(513, 1244, 128, 128, 0) == 6
+    assert plan(513, 1244, 129, 64, 0) == 0 and plan(500, 1244, 128, 64, 0) == 0                # K > 128 / F not 64 n + 1: the batched tiles
+    groups = lambda n: 4 | (n << 8)
+    assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2
+    assert plan(513, 0, 128, 64, 0) == -1
+    try:
+        assert lib.gccnmf_set_tuning(16, 0) == 0 and lib.gccnmf_set_tuning(17, 2) == 0
+        assert plan(513, 1244, 128, 26, 0) == 4 and plan(513, 1244, 64, 5, 0) == 4
+        assert plan(257, 500, 128, 26, 0) == 0                                                  # 4 slabs cannot hold the tail sums of 128 atoms
+    finally:
+        lib.gccnmf_set_tuning(16, 1)
+        lib.gccnmf_set_tuning(17, 1)
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
