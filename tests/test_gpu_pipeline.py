@@ -66,15 +66,26 @@ def test_dev1_against_reference_golden(dev1, K):
           (K, rel(W[0][:, ::sub], g['W_sub']), rel(H[0][::sub, :], g['H_sub']), flips, worst, rms))
 
 
-@pytest.mark.parametrize('K', [128, 1024])
-def test_all_reference_mixtures_batched(K):
+@pytest.mark.parametrize('K,launches', [(128, 'auto'), (128, 'fused'), (128, 'four'), (1024, 'auto')])
+def test_all_reference_mixtures_batched(K, launches):
     """The five other reference mixtures as ONE batch of 5 (+ dev1), K = 128 and K = 1024: TDOA indexes exact for every file.
     Their sources sit within 4 TDOA bins of each other (d = 1 m assumed, real spacing 5 cm), which makes
-    this the sharp test of the f32 angular spectrum."""
+    this the sharp test of the f32 angular spectrum.  K = 128 also with both short-dictionary fused launches forced (tuning keys 16 / 17 = 2:
+    K1 + K2 on column tiles, K3 + K4a on bin slabs, csrc/direct.hip) and with neither: the same bars against the reference's outputs."""
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
     names = ['dev1_female3_liverec_130ms_1m'] + WAVS
     xs = np.stack([golden_wav(w)[0] for w in names])
     e = engine(xs.shape[2], dictionarySize=K, numIterations=100, batch=len(names))
-    y = e.separate(xs)
+    try:
+        if launches != 'auto':
+            v = 2 if launches == 'fused' else 0
+            assert lib.gccnmf_set_tuning(16, v) == 0 and lib.gccnmf_set_tuning(17, v) == 0
+            assert lib.gccnmf_klnmf_plan(e.g.F, e.g.N, K, len(names), 0) == (6 if launches == 'fused' else 0)
+        y = e.separate(xs)
+    finally:
+        lib.gccnmf_set_tuning(16, 1)
+        lib.gccnmf_set_tuning(17, 1)
     idx = e.get_tdoa_indexes()
     for i, w in enumerate(names):
         g = golden('%s_hop256_K%d' % (w, K)) if i else golden('dev1_hop256_K%d' % K)
