@@ -42,7 +42,8 @@ long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
 extern "C" {
-int gccnmf_version(void) { return 104; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT
+int gccnmf_version(void) { return 105; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT,
+                                           // fused short-dictionary launches (tuning keys 16 / 17, gccnmf_klnmf_plan, GCCNMF_FLAG_GROUPS)
 
 int gccnmf_set_tuning(int key, int value) {
     if (key == 1) {
