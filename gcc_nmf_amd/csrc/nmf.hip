@@ -763,15 +763,31 @@ static int launch_wh_updh(const NmfGeom& g, const float* V, const float* W, floa
 // K3 and K4a as ONE launch (gccnmf_whdiv_rht_kernel: 64-bin slabs with their W rows in registers), K <= 128.
 // Every slab workgroup walks ALL column tiles of its file, so the launch costs one "round" (two workgroups per CU, 512 at a time) however
 // few workgroups it holds: measured at K = 128, N = 1244 a round takes 184 us against 3.72 us per file for the two launches it replaces
-// (64 files: 184 against 238 us; 40 files: 184 against 149).  Both scale alike with K and N, so the choice is a ratio: the fused launch
-// runs when batch * slabs / 8 > 49.5 * rounds.  (GCCNMF_FLAG_GROUPS: the file groups that run side by side share the rounds.)
-static bool fused_whdiv_rht(const NmfGeom& g, int batch, int flags) {
+// (64 files: 184 against 238 us; 40 files: 184 against 149).  Both scale alike with K and N, so the choice is a ratio.  Returns the number of
+// files (from the front of the batch) that take the slab launch: all of them, none, or whole rounds' worth with the REST of the files on
+// the two launches behind it (72 files: 64 + 8 -> 184 + 40 us against 268 for the two launches over all of them, 368 for two slab rounds).
+// (GCCNMF_FLAG_GROUPS: the file groups that run side by side share the rounds; they are not split.)
+static int fused_whdiv_rht_files(const NmfGeom& g, int batch, int flags) {
     if (!gccnmf_tune_fused_k34 || gccnmf_tune_tile_policy != 0 || direct_path(g, batch) || batch < 2 || !g.tail || g.Fm < 64 || g.Fm > 512 ||
         (g.Fm % 64) != 0 || g.K > 128 || (g.Fm / 64) * 16 < 32 * gccnmf_ceil_div(g.K, 32))
-        return false;
-    if (gccnmf_tune_fused_k34 == 2) return true;
-    const long slabs = g.Fm / 64, wgs = (long)batch * slabs * concurrent_groups(flags), rounds = (wgs + 511) / 512;
-    return 8 * 495 * rounds < 10 * wgs;
+        return 0;
+    if (gccnmf_tune_fused_k34 == 2) return batch;
+    const long slabs = g.Fm / 64, groups = concurrent_groups(flags), wgs = (long)batch * slabs * groups, rounds = (wgs + 511) / 512;
+    const long per_round = 512 / slabs;                          // files per round
+    // in hundredths of a microsecond: 3.72 us x slabs / 8 per file on the two launches, 184 us per round, 10 us for the extra launch pair
+    const long two = 372 * slabs / 8;
+    long best = two * batch * groups, head = 0;                  // all files on the two launches
+    if (18400 * rounds < best) {
+        best = 18400 * rounds;
+        head = batch;
+    }
+    if (groups == 1) {
+        const long r = batch / per_round;                        // whole rounds of files, the rest behind them on the two launches
+        // (+ 10 %: the two launches are dearer per file on a small rest than the straight line says -- 104 files: 64 + 40 measured 717 us
+        // per iteration against 699 for two slab rounds)
+        if (r >= 1 && r * per_round < batch && 11 * (18400 * r + two * (batch - r * per_round) + 1000) < 10 * best) head = r * per_round;
+    }
+    return (int)head;
 }
 static int launch_whdiv_rht(const NmfGeom& g, const float* V, const float* W, const float* H, float* U, float* rowsumH, int batch, hipStream_t s) {
     WhdivRhtArgs a = {};
@@ -809,7 +825,9 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     float* parts = hscale + (long)batch * g.Kp;                                   // batch == 1 only
     float* rowsum_parts = parts + GCCNMF_SPLITS * (g.sV > g.sU ? g.sV : g.sU);
     float* direct_base = batch == 1 ? rowsum_parts + GCCNMF_SPLITS * (long)g.Kp : parts;
-    const bool fused12 = fused_wh_updh(g, batch, flags), fused34 = fused_whdiv_rht(g, batch, flags);
+    const bool fused12 = fused_wh_updh(g, batch, flags);
+    const int head34 = fused_whdiv_rht_files(g, batch, flags), rest34 = batch - head34;      // files on the slab launch | behind it on the two launches
+    const bool fused34 = head34 > 0;
     if (direct_path(g, batch)) {
         const DirectBufs d = direct_bufs(g, direct_base, batch);
         switch (stage) {
@@ -853,11 +871,17 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             if (fused12) return GCCNMF_OK;                                                                             // done by stage 1
             return launch_update_h(g, W, g.sW, R, H, hscale, g.Kp, colsumW, g.Kp, alpha, eps, batch, xcd, s);
         case 3:
-            if (fused34) return launch_whdiv_rht(g, V, W, H, U, rowsumH, batch, s);                                      // K3 + K4a
+            if (fused34) {                                                                                             // K3 + K4a
+                const int rc = launch_whdiv_rht(g, V, W, H, U, rowsumH, head34, s);
+                if (rc || !rest34) return rc;
+                return launch_wh_div(g, V + head34 * g.sV, W + head34 * g.sW, g.sW, H + head34 * g.sH, nullptr, 0, R + head34 * g.sV, rest34, xcd, s);
+            }
             if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, s);
             return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
         case 4:
-            if (fused34) return GCCNMF_OK;                                                                             // done by stage 3
+            if (fused34)                                                                                               // done by stage 3 ...
+                return rest34 ? launch_rht(g, R + head34 * g.sV, H + head34 * g.sH, U + head34 * g.sU, rowsumH + (long)head34 * g.Kp, rest34, xcd, s)
+                              : GCCNMF_OK;                                                                             // ... but for the rest
             if (split_rht) return launch_rht_split(g, R, H, parts, rowsum_parts, s);
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
             return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
@@ -881,7 +905,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     const NmfGeom g = make_geom(F, N, K);
-    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht(g, batch, flags) ? 4 : 0);
+    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht_files(g, batch, flags) > 0 ? 4 : 0);
 }
 
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,

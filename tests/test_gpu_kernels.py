@@ -496,6 +496,42 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
     assert np.array_equal(res['fused-some'][0][0], res['fused'][0][B - 1]) and np.array_equal(res['fused-some'][1][2], res['fused'][1][2])
 
 
+def test_klnmf_slab_launch_for_whole_rounds_and_the_rest_on_the_two_launches(hip):
+    """70 files at K = 32: the cost model of tuning key 17 puts one whole round of slab workgroups (64 files) on the fused K3 + K4a launch
+    and the remaining 6 files on the two launches behind it; every file against the oracle, and against the four-launch form."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import Geometry, padded, klnmf_initial_factors
+    F, T, K, B = 513, 20, 32, 70
+    N = 2 * T
+    g = Geometry(F, T, K)
+    rng = np.random.RandomState(70)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    res = {}
+    try:
+        for name, k16, k17 in [('four-launch', 0, 0), ('auto', 0, 1)]:
+            assert lib.gccnmf_set_tuning(16, k16) == 0 and lib.gccnmf_set_tuning(17, k17) == 0
+            assert lib.gccnmf_klnmf_plan(F, N, K, B, 0) == (4 if k17 else 0)
+            Vd = padded(V, (B, g.Fp, g.Np), 'cuda')
+            Wd = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
+            Hd = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
+            ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
+            assert lib.gccnmf_klnmf(Vd.data_ptr(), Wd.data_ptr(), Hd.data_ptr(), ws.data_ptr(), F, N, K, B, 5, 0.0, 1e-16, 0, stream()) == 0
+            torch.cuda.synchronize()
+            res[name] = (Wd.cpu().numpy(), Hd.cpu().numpy())
+    finally:
+        lib.gccnmf_set_tuning(16, FUSED_K12_DEFAULT)
+        lib.gccnmf_set_tuning(17, FUSED_K34_DEFAULT)
+    W, H = res['auto']
+    assert np.isfinite(W).all() and np.isfinite(H).all()
+    assert not W[:, F:].any() and not W[:, :, K:].any() and not H[:, K:].any() and not H[:, :, N:].any()
+    for b in (0, 63, 64, 69):
+        Wr, Hr = O.performKLNMF(V[b], K, 5, 0.0)
+        assert rel(W[b, :F, :K], Wr) < 1e-4 and rel(H[b, :K, :N], Hr) < 1e-4, (b, rel(W[b, :F, :K], Wr), rel(H[b, :K, :N], Hr))
+    assert rel(W, res['four-launch'][0]) < 2e-5 and rel(H, res['four-launch'][1]) < 2e-5
+    assert np.array_equal(W[64:], res['four-launch'][0][64:]) and np.array_equal(H[64:], res['four-launch'][1][64:])      # the rest: the same launches
+
+
 def hip_geometry(F, T, K):
     from gcc_nmf_amd.engine import Geometry
     return Geometry(F, T, K)

@@ -92,7 +92,7 @@ def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
     plan = lib.gccnmf_klnmf_plan
     assert plan(513, 1244, 1024, 1, 0) == 1 and plan(513, 1244, 1024, 4, 0) == 1 and plan(513, 1244, 1024, 64, 0) == 0     # direct path: up to 4 files
     assert plan(513, 1244, 128, 64, 0) == 6 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
-    assert plan(513, 1244, 128, 96, 0) == 2 and plan(513, 1244, 128, 128, 0) == 6
+    assert plan(513, 1244, 128, 96, 0) == 6 and plan(513, 1244, 128, 128, 0) == 6                # 96: a round of 64 files on the slabs, 32 behind it
     assert plan(513, 1244, 129, 64, 0) == 0 and plan(500, 1244, 128, 64, 0) == 0                # K > 128 / F not 64 n + 1: the batched tiles
     groups = lambda n: 4 | (n << 8)
     assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2
