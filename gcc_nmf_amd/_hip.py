@@ -93,6 +93,7 @@ SIGNATURES = {
     'gccnmf_gemm_direct': (c_int, [ctypes.POINTER(DirectGemm), c_int, c_int, c_void_p]),
     'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),
     'gccnmf_debug_mfma_peak': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'gccnmf_debug_gemm_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P_INT, P_INT, c_int]),
     'gccnmf_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p]),
 }
@@ -122,13 +123,15 @@ def lib():
         try:
             fn = getattr(handle, name)
         except AttributeError:
+            if os.environ.get('GCCNMF_HIP_LIB'):      # an A/B build of another revision: entry points it lacks are simply not callable
+                continue
             raise HipLibraryError('%s does not export %s (stale build? re-run make -C gcc_nmf_amd/csrc)' % (LIB_PATH, name))
         fn.restype = restype
         fn.argtypes = argtypes
     # A/B runs without code changes: GCCNMF_TUNE="9=2,8=1" applies gccnmf_set_tuning(key, value) pairs at load time
     for kv in filter(None, os.environ.get('GCCNMF_TUNE', '').split(',')):
         key, value = [int(v) for v in kv.split('=')]
-        if handle.gccnmf_set_tuning(key, value) != 0:
+        if handle.gccnmf_set_tuning(key, value) != 0 and not os.environ.get('GCCNMF_HIP_LIB'):
             raise HipLibraryError('GCCNMF_TUNE: gccnmf_set_tuning(%d, %d) was rejected' % (key, value))
     _lib = handle
     return _lib

@@ -1,4 +1,4 @@
-// Direct-to-LDS variant of the throughput GEMM tile (512 x 64 per workgroup, 128 x 64 per wave):
+// The throughput GEMM tile (512 x 64 per workgroup, 128 x 64 per wave; narrow items 512 x 32) on LDS-DMA:
 // operand tiles go global -> LDS by `global_load_lds_dwordx4` (LDS-DMA: no VGPR staging, no ds_write pass), and the
 // reduction-contiguous operands are read back as ds_read_b128 fragments.
 //
@@ -16,6 +16,7 @@
 // Measurement tooling lives here too: gccnmf_debug_set_trace (per-workgroup timeline, scripts/ktrace.py) and the
 // GEMM_DMA_PROBE build (per-phase cycle counts of the k-tile, scripts/ktrace.py --probe).
 #pragma once
+#include <mutex>
 #include <type_traits>
 #include "gemm_mfma.h"
 
@@ -57,6 +58,14 @@ __device__ __forceinline__ void gemm_dma16_lanes(const float* wave_uniform_base,
 }
 
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 2) & 3; }
+
+// The thread index through an asm statement the compiler cannot see through: values derived from it are recomputed where they are
+// needed instead of being kept in registers as loop invariants.
+__device__ __forceinline__ int gemm_opaque_tid() {
+    int t;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(threadIdx.x));
+    return t;
+}
 
 // MFMA fragment reads as inline asm: the compiler neither sees them as LDS reads (so it does not drain the LDS-DMA queue
 // in front of them) nor waits for them -- every use is preceded by gemm_wait_lds() + gemm_tie() on the destination.
@@ -131,6 +140,10 @@ struct GemmFrag<true, NT, ROWS> {
 #pragma unroll
         for (int m = 0; m < NT; ++m) gemm_tie(v[m]);
     }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) v[m] = gemm_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __device__ __forceinline__ float get(int m, int e) const { return v[m][e]; }
     __device__ __forceinline__ void scale(const gemm_f32x4& s) {
 #pragma unroll
@@ -154,6 +167,12 @@ struct GemmFrag<false, NT, ROWS> {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int h = 0; h < NT / 2; ++h) gemm_tie(v[e][h]);
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int h = 0; h < NT / 2; ++h) v[e][h] = gemm_f32x2{0.f, 0.f};
     }
     __device__ __forceinline__ float get(int m, int e) const { return v[e][m >> 1][m & 1]; }
     __device__ __forceinline__ void scale(const gemm_f32x4& s) {
@@ -372,13 +391,68 @@ __device__ __forceinline__ void gemm_epilogue_update_w_full(const GemmArgs& p, i
     }
 }
 
-// TM = 32-row MFMA tiles per wave: 4 = the 512 x 64 throughput tile; 2 = the HALF-HEIGHT tile (256 x 64, 64 x 64 per wave) that the
-// launcher gives to the files of a launch's last, partial round (same k order per output element: bitwise the same result).
-template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM = 4>
+// ---- the work list of a launch ---------------------------------------------------------------------------------------------
+// A launch is an ORDERED list of work items per XCD (GemmArgs.lists = 8: XCD x = blockIdx & 7 serves list x; 1: one list), taken in
+// order -- by the hardware dispatcher (classic grid: workgroup b takes item b >> 3 of list b & 7) or by resident workgroups through
+// a ticket counter (persistent grid, below).  An item is one output tile, computed by ONE workgroup in the fixed k order, so a
+// file's bits depend neither on who takes an item nor on the form it has.  Three kinds, longest first:
+//   wide    512 x 64   items 0 .. len - split - 1 of a list: its chunk [list * cw, ...) of the file-major list of wide tiles
+//                      (files in the class order 0, 8, 16, ... | 1, 9, ... so that a file's tiles share one XCD's L2)
+//   halves  512 x 32   the last `split` wide tiles of the chunk as two NARROW items each (left / right 32 columns): finer grain for
+//                      the end of a launch that would otherwise leave CUs idle (host-side list-scheduling model, gemm_dma_plan)
+//   ragged  512 x 32   the last column tile of a file when at most 32 of its 64 columns exist (N = 1244 = 19 x 64 + 28): half the
+//                      matrix work of the padded tile it replaces (rag = 1; chunk [list * cr, ...) of the file-major list)
+// A narrow item runs the same loop without the MFMAs of the right column block: same k order per element -> same bits.
+__host__ __device__ __forceinline__ int gemm_dma_list_file(const GemmArgs& p, int q) {      // position q in the class order -> file
+    if (p.lists != 8) return q;
+    const int n_full = p.batch >> 3, rem = p.batch & 7, big = rem * (n_full + 1);
+    const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
+    return cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
+}
+__host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int list, int t, int& file, int& tm, int& col0, int& nw) {
+    const int wt = p.tiles_m * p.wide_n;                      // wide tiles per file
+    const int base_w = list * p.cw;
+    const int len = min(max(p.batch * wt - base_w, 0), p.cw), s = min(p.split, len);
+    int q;
+    if (t < len + s) {
+        int idx, half = 0;
+        if (t < len - s) {
+            idx = base_w + t;
+            nw = 2;
+        } else {
+            const int j = t - (len - s);
+            idx = base_w + (len - s) + (j >> 1);
+            half = j & 1;
+            nw = 1;
+        }
+        q = idx / wt;
+        const int w = idx - q * wt;
+        tm = w / p.wide_n;
+        col0 = (w - tm * p.wide_n) * 64 + 32 * half;
+    } else {
+        const int r = t - (len + s), base_r = list * p.cr;
+        const int lenr = min(max(p.batch * p.rag * p.tiles_m - base_r, 0), p.cr);
+        if (r >= lenr) return false;
+        const int idx = base_r + r;
+        q = idx / p.tiles_m;
+        tm = idx - q * p.tiles_m;
+        col0 = (p.tiles_n - 1) * 64;
+        nw = 1;
+    }
+    file = gemm_dma_list_file(p, q) + p.file0;
+    return true;
+}
+
+// The throughput tile: 512 x 64 per workgroup, 128 x 64 per wave (TM = 4 MFMA row tiles x 2 column blocks).
+// NARROW: the instantiation also carries the 512 x 32 form of the main loop (items with nw = 1).
+// PERSISTENT grid (p.tickets != nullptr): 64 resident workgroups per list (two per CU) pull items through a ticket counter until the list
+// is empty -- work-conserving whatever the items cost; the ticket of the NEXT item is taken at the start of the current one, and the
+// next tile's first LDS-DMA pieces are issued BEFORE the current tile's epilogue (p.prefetch), so a workgroup's matrix pipe does not
+// wait for a prologue between two tiles.  The last workgroup to leave resets the counters (the next launch on the stream finds zeros).
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, bool NARROW>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
-    static_assert(TM == 4 || TM == 2, "");
-    static_assert(TM == 4 || EPI != EPI_UPDW, "the fused W update owns all rows of its atoms: full-height tiles only");
-    constexpr int BK = 16, BM = 128 * TM, BN = 64, RW = 32 * TM;      // RW: rows per wave
+    static_assert(!NARROW || EPI != EPI_UPDW, "the fused W update owns all rows and all 64 atoms of its tile");
+    constexpr int TM = 4, BK = 16, BM = 128 * TM, BN = 64, RW = 32 * TM;      // RW: rows per wave
     constexpr int NA = 2 * TM;                                         // 1 KB LDS-DMA pieces of the A tile per wave
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
@@ -386,97 +460,75 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
     __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * BM : 4];   // lean epilogue row factors
     __shared__ unsigned s_arrivals;                  // split barrier of the main loop: 4 arrivals per k-tile
+    __shared__ int s_ticket[2];                      // persistent grid: the next item of this workgroup (alternating slots)
 
-    const int tiles = p.tiles_m * p.tiles_n;
-    int file, tile;
-    if (p.xcd_affine) {
-        // XCD x owns the contiguous chunk [x * chunk, (x+1) * chunk) of the tile list (chunk = xcd_affine = ceil(total / 8)) taken in
-        // the file order 0, 8, 16, ... | 1, 9, ... : balanced to one tile whatever the batch (25 files used to put 4 files = 80 tiles
-        // on XCD 0 and 3 on the others), a file still sits on one XCD (or straddles two neighbours), and for a multiple of 8 files it
-        // is exactly the map of rounds 1-2 (XCD x <- files x, x+8, ...), which is 3 % faster at 64 files than contiguous files per
-        // XCD (K3 0.645 vs 0.668 ms, A/B on one box: profiles/r03_ab_xcd_map.txt)
-#ifdef GEMM_XCD_FILE_GRANULAR      // A/B build: the file-granular map of rounds 1-2 (file = xcd + 8 j)
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        file = xcd + 8 * (slot / tiles);
-        tile = slot % tiles;
-        if (file >= p.batch) return;
-#else
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int idx = xcd * p.xcd_affine + slot;
-        if (idx >= p.batch * tiles) return;
-        // position q in the file order 0, 8, 16, ... | 1, 9, 17, ... | ... (files of one residue class mod 8 are neighbours)
-        const int q = idx / tiles;
-        tile = idx - q * tiles;
-        const int n_full = p.batch >> 3, rem = p.batch & 7, big = rem * (n_full + 1);
-        const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
-        file = cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
-#endif
-    } else {
-        file = blockIdx.x / tiles;
-        tile = blockIdx.x - file * tiles;
-    }
-    file += p.file0;
-    // (the integer divisions above run on the VALU: without the readfirstlanes every value derived from file / tile -- all
-    // row pointers, descriptors and scalar offsets below -- stays in VGPRs and each buffer access becomes a waterfall loop)
-    file = __builtin_amdgcn_readfirstlane(file);
-    const int tm = __builtin_amdgcn_readfirstlane(tile / p.tiles_n), tn = __builtin_amdgcn_readfirstlane(tile) - tm * p.tiles_n;
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
+    // Per-lane values are RE-DERIVED per item from an opaque copy of the thread index (gemm_opaque_tid): as loop invariants of the item
+    // loop they would stay live across the epilogue, whose 128 accumulators + two tile pairs of inputs leave no registers for them.
+    int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
-
-    if (p.trace && tid == 0) {
-        p.trace[8 * blockIdx.x + 0] = p.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
-    }
     const int wm = wave, wn = 0;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int arow = wm * RW + l31, bcol = wn * 64 + l31;
+    int l31 = lane & 31, hh = lane >> 5;
+    const bool persistent = p.tickets != nullptr;
+    const int list = p.lists == 8 ? (int)(blockIdx.x & 7) : 0;
+    int t = p.lists == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;            // first item: static (the counter starts behind the resident workgroups)
 
-    const float* __restrict__ A = p.A + file * p.sA;
-    const float* __restrict__ B = p.B + file * p.sB;
-    const float* __restrict__ bscale = (SCALE && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
-    const bool wave_active = (row0 + wm * RW) < p.M;
-    const bool do_tail = TAIL && (tm == 0);
-    const bool do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
-
-    // per-lane source offsets (elements) of this wave's DMA pieces: NA of A, 1 of B
-    unsigned offA[NA], offB;                                           // bytes from the (wave-uniform) k-tile origin
+    // ---- per-item state (set by take_item) ----
+    int file = 0, tm = 0, col0 = 0, nw = 2, row0 = 0;
+    const float* __restrict__ A = nullptr;
+    const float* __restrict__ B = nullptr;
+    const float* __restrict__ bscale = nullptr;
+    const float* __restrict__ tail_src = nullptr;
+    bool wave_active = false, do_tail = false, do_rowsum = false;
+    unsigned offA[NA], offB = 0;                                       // per-lane source offsets (bytes from the wave-uniform k-tile origin) of this wave's DMA pieces
+    auto take_item = [&](const int ticket) -> bool {
+        int f_, tm_, c_, nw_;
+        if (!gemm_dma_item(p, list, ticket, f_, tm_, c_, nw_)) return false;
+        // (the integer divisions of the decode run on the VALU: without the readfirstlanes every value derived from file / tile -- all
+        // row pointers, descriptors and scalar offsets below -- stays in VGPRs and each buffer access becomes a waterfall loop)
+        file = __builtin_amdgcn_readfirstlane(f_);
+        tm = __builtin_amdgcn_readfirstlane(tm_);
+        col0 = __builtin_amdgcn_readfirstlane(c_);
+        nw = NARROW ? __builtin_amdgcn_readfirstlane(nw_) : 2;
+        row0 = tm * BM;
+        A = p.A + file * p.sA;
+        B = p.B + file * p.sB;
+        bscale = (SCALE && p.bscale) ? p.bscale + file * p.s_bscale : nullptr;
+        wave_active = (row0 + wm * RW) < p.M;
+        do_tail = TAIL && (tm == 0);
+        do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
+        tail_src = A + (long)p.tail_row * p.lda;
+        return true;
+    };
+    auto set_offsets = [&](const int lane) {                           // this wave's DMA source offsets for the current item
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int piece = wave * NA + i;                               // 1 KB pieces of the A tile
-        if (A_KC) {
-            const int row = piece * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(piece * 16 + (lane >> 2));
-            offA[i] = 4u * (unsigned)(min(row0 + row, p.a_clamp) * p.lda + 4 * c);
-        } else {
-            constexpr int PPR = BM / 256;                              // pieces per k row of the [16][BM] image
-            const int kk = piece / PPR, col = (piece % PPR) * 256 + lane * 4;
-            offA[i] = 4u * (unsigned)(kk * p.lda + min(row0 + col, p.a_clamp));
+        for (int i = 0; i < NA; ++i) {
+            const int piece = wave * NA + i;                               // 1 KB pieces of the A tile
+            if (A_KC) {
+                const int row = piece * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(piece * 16 + (lane >> 2));
+                offA[i] = 4u * (unsigned)(min(row0 + row, p.a_clamp) * p.lda + 4 * c);
+            } else {
+                constexpr int PPR = BM / 256;                              // pieces per k row of the [16][BM] image
+                const int kk = piece / PPR, col = (piece % PPR) * 256 + lane * 4;
+                offA[i] = 4u * (unsigned)(kk * p.lda + min(row0 + col, p.a_clamp));
+            }
         }
-    }
-    if (B_KC) {
-        const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(row);
-        offB = 4u * (unsigned)(min(col0 + row, p.b_clamp) * p.ldb + 4 * c);
-    } else {
-        const int kk = wave * 4 + (lane >> 4), col = (lane & 15) * 4;
-        offB = 4u * (unsigned)(kk * p.ldb + min(col0 + col, p.b_clamp));
-    }
+        if (B_KC) {
+            const int row = wave * 16 + (lane >> 2), c = (lane & 3) ^ gemm_swz(row);
+            offB = 4u * (unsigned)(min(col0 + row, p.b_clamp) * p.ldb + 4 * c);
+        } else {
+            const int kk = wave * 4 + (lane >> 4), col = (lane & 15) * 4;
+            offB = 4u * (unsigned)(kk * p.ldb + min(col0 + col, p.b_clamp));
+        }
+    };
 
     f32x16 acc[TM][2];
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
     const int nkt = (p.Kd + BK - 1) / BK;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(gemm_lds_ptr)smem);
     // the two 64-byte side chunks (tail row of A, row scale of B) sit next to each other behind the B tile: ONE piece of wave 0,
-    // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk
-    // fetched by wave 0: lanes 0-3 the tail chunk, lanes 4-7 the scale chunk -- both land at (tail chunk) + 16 * lane
-    const float* __restrict__ tail_src = A + (long)p.tail_row * p.lda;
-    const unsigned side_off = 16u * (unsigned)(lane & 3);
+    // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk -- both land at (tail chunk) + 16 * lane
+    unsigned side_off = 0;
 
     // One 1 KB LDS-DMA piece of tile kt into staging buffer `buf`: 0 .. NA-1 = this wave's share of A, NA = of B, NA+1 = the tail row
     // chunk / the row-scale chunk.  (Dealt out between the MFMAs of the main loop: SPREAD below.)
@@ -520,13 +572,22 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 
     const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)&s_arrivals;
     // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
-    const unsigned oA0 = A_KC ? 4 * (arow * 16 + 4 * ((0 + hh) ^ gemm_swz(arow))) : 4 * (4 * (0 + hh) * BM + arow);
-    const unsigned oA1 = A_KC ? 4 * (arow * 16 + 4 * ((2 + hh) ^ gemm_swz(arow))) : 4 * (4 * (2 + hh) * BM + arow);
-    const unsigned oB0 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((0 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (0 + hh) * BN + bcol));
-    const unsigned oB1 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((2 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (2 + hh) * BN + bcol));
-    const int tj = tid & 63, tg = tid >> 6;                        // tail row: 4 thread groups x 4 reduction steps each
-    const unsigned oTB = 4 * SA + (B_KC ? 4 * (tj * 16 + 4 * (tg ^ gemm_swz(tj))) : 4 * (4 * tg * BN + tj));
-    const unsigned oRS = 4 * SA + 4 * ((tid >> 2) * 16 + 4 * (tid & 3));   // row sums: 4 threads per atom row, one chunk each
+    unsigned oA0 = 0, oA1 = 0, oB0 = 0, oB1 = 0, oTB = 0, oRS = 0;
+    const int tg = wave;                                           // tail row: 4 thread groups (= waves) x 4 reduction steps each
+    auto set_lane_constants = [&](const int tid_) {
+        tid = tid_;
+        lane = tid_ & 63;
+        l31 = lane & 31;
+        hh = lane >> 5;
+        const int arow = wm * RW + l31, bcol = wn * 64 + l31, tj = lane;
+        side_off = 16u * (unsigned)(lane & 3);
+        oA0 = A_KC ? 4 * (arow * 16 + 4 * ((0 + hh) ^ gemm_swz(arow))) : 4 * (4 * (0 + hh) * BM + arow);
+        oA1 = A_KC ? 4 * (arow * 16 + 4 * ((2 + hh) ^ gemm_swz(arow))) : 4 * (4 * (2 + hh) * BM + arow);
+        oB0 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((0 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (0 + hh) * BN + bcol));
+        oB1 = 4 * SA + (B_KC ? 4 * (bcol * 16 + 4 * ((2 + hh) ^ gemm_swz(bcol))) : 4 * (4 * (2 + hh) * BN + bcol));
+        oTB = 4 * SA + (B_KC ? 4 * (tj * 16 + 4 * (tg ^ gemm_swz(tj))) : 4 * (4 * tg * BN + tj));
+        oRS = 4 * SA + 4 * ((tid_ >> 2) * 16 + 4 * (tid_ & 3));   // row sums: 4 threads per atom row, one chunk each
+    };
 
     auto read_group0 = [&](const unsigned lds) {                    // lds = byte address of the staging buffer
         if (wave_active) {
@@ -590,34 +651,12 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         }
         if (B_KC) gemm_tie(rs4);
     };
-    auto mma = [&](const GemmFrag<A_KC, TM, BM>& a, const GemmFrag<B_KC, 2, BN>& b, const int e, const int m) {
+    // NW = column blocks of the item: 2 = the 512 x 64 tile, 1 = a narrow (512 x 32) item -- the right block's MFMAs are not issued
+    auto mma = [&](auto nw_c, const GemmFrag<A_KC, TM, BM>& a, const GemmFrag<B_KC, 2, BN>& b, const int e, const int m) {
+        constexpr int NW = decltype(nw_c)::value;
         acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(0, e), acc[m][0], 0, 0, 0);
-        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(1, e), acc[m][1], 0, 0, 0);
+        if constexpr (NW == 2) acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.get(m, e), b.get(1, e), acc[m][1], 0, 0, 0);
     };
-
-    // row factors of the lean epilogue (visible after the prologue barrier; read only after the main loop)
-    if constexpr (EPI == EPI_STORE || EPI == EPI_UPDH) {
-#pragma unroll
-        for (int i = 0; i < BM / 256; ++i) {
-            const int lr = tid + 256 * i, row = min(row0 + lr, p.M - 1);
-            s_rowvec[lr] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
-            if (EPI == EPI_UPDH) {
-                const float rd = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
-                s_rowvec[BM + lr] = p.E1 ? p.E1[file * p.sE1 + row] * rd : rd;
-            }
-        }
-    }
-    if (tid == 0) s_arrivals = 0;
-    if (SCALE) {
-        if (!bscale && tid < 2 * BK) smem[(tid >> 4) * SBUF + SA + SB + BK + (tid & 15)] = 1.f;       // no row scale: both chunks stay 1
-    }
-    // prologue: tile 0 -> buffer 0, group 0 of tile 0 into registers
-#pragma unroll
-    for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    read_group0(lds0);
-    wait_group0();
 
     // One k-tile, software-pipelined ACROSS the workgroup barrier so that no wave has an MFMA-free stretch per tile (two
     // co-resident workgroups fall into lock-step -- the one behind gets the whole matrix pipe whenever the leader is busy
@@ -632,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     // re-fetch the last tile (valid addresses, never read): cheaper than a branch around every piece.
 #ifdef GEMM_DMA_PROBE
     // build-time instrumentation (make variant X=-DGEMM_DMA_PROBE, scripts/ktrace.py --probe): shader-clock cycles per
-    // phase of the k-tile, summed over the main loop, per wave
+    // phase of the k-tile, summed over the main loops of all items of the workgroup, per wave
     unsigned long long probe[7] = {0, 0, 0, 0, 0, 0, 0};
 #define GEMM_PROBE(i_) const unsigned long long pt##i_ = __builtin_amdgcn_s_memtime()
 #define GEMM_PROBE_DECL(i_) unsigned long long pt##i_ = 0
@@ -642,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 #define GEMM_PROBE_DECL(i_)
 #define GEMM_PROBE_SET(i_)
 #endif
-    auto step = [&](auto cur_c, const int kt) {
+    auto step = [&](auto cur_c, auto nw_c, const int kt) {
         constexpr int CUR = decltype(cur_c)::value;
         const unsigned ldsC = lds0 + 4 * CUR * SBUF, ldsN = lds0 + 4 * (CUR ^ 1) * SBUF;
         const int ktn = min(kt + 1, nkt - 1);
@@ -661,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int m = 0; m < TM; ++m) {
-                    mma(a0, b0, e, m);
+                    mma(nw_c, a0, b0, e, m);
                     const int slot = e * TM + m;
                     if (SPREAD == 1 && slot < NPIECES) {
                         dma_piece(slot, ktn, CUR ^ 1);
@@ -723,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             }
             if (wave_active) {
 #pragma unroll
-                for (int m = 0; m < TM; ++m) mma(a1, b1, e, m);
+                for (int m = 0; m < TM; ++m) mma(nw_c, a1, b1, e, m);
             }
         }
         if (TAIL) {
@@ -753,162 +792,312 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
     };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        step(std::integral_constant<int, 0>{}, kt);
-        if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, kt + 1);
-    }
-    __syncthreads();                      // the epilogues reuse the staging buffers
-#ifdef GEMM_DMA_PROBE
-    if (p.trace && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) p.trace[8 * ((long)gridDim.x + blockIdx.x * 4 + wave) + i] = (long long)probe[i];
-    }
-#endif
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    auto main_loop = [&](auto nw_c) {
+        for (int kt = 0; kt < nkt; kt += 2) {
+            step(std::integral_constant<int, 0>{}, nw_c, kt);
+            if (kt + 1 < nkt) step(std::integral_constant<int, 1>{}, nw_c, kt + 1);
+        }
+    };
 
-    if constexpr (EPI == EPI_UPDW) {
-        // launch_rht_update_w guarantees M % 128 == 0 and N % 64 == 0 (a second, generic variant in this kernel would
-        // double the live ranges of the accumulators and spill the main loop)
-        gemm_epilogue_update_w_full<TAIL>(p, file, col0, tid, wm, l31, hh, wave_active, acc, tail_acc, rowsum_acc, smem);
-        if (p.trace) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-        }
-        return;
+    if (SCALE) {
+        if (!p.bscale && tid < 2 * BK) smem[(tid >> 4) * SBUF + SA + SB + BK + (tid & 15)] = 1.f;       // no row scale: both chunks stay 1
     }
-    if (wave_active) {
-        const int row_w = row0 + wm * RW;                           // wave-uniform
-        bool lean = false;
-        if constexpr (EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH) {
-            lean = row_w + RW <= p.M;                               // all tile pairs of the wave have all their rows
-            if (lean) {
-                GemmEpiloguePair<EPI, BM> e0, e1;
-                const int ca = col0 + l31, tr = wm * RW;
-                const bool oka = ca < p.N, okb = ca + 32 < p.N;
-                const long cb = 4L * p.ldc * (p.M + (TAIL ? 1 : 0));
-                float ba = 0.f, bb = 0.f;
-                e0.load(p, file, row_w, hh, ca, cb);
-                e1.load(p, file, row_w + 32, hh, ca, cb);
-                if (EPI != EPI_DIV && p.ktailA) {
-                    ba = p.ktailB[file * p.s_ktailB + min(ca, p.N - 1)];
-                    bb = p.ktailB[file * p.s_ktailB + min(ca + 32, p.N - 1)];
-                }
-                e0.finish(p, file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
-                if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-                if constexpr (TM == 4) e0.load(p, file, row_w + 64, hh, ca, cb);
-                e1.finish(p, file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1], oka, okb, cb);
-                if constexpr (TM == 4) {
-                    e1.load(p, file, row_w + 96, hh, ca, cb);
-                    e0.finish(p, file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
-                    e1.finish(p, file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
-                }
-                if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
-            }
+    bool have = take_item(t);
+    if (have) set_offsets(lane);
+    bool prefetched = false;                           // the first k-tile of the current item is already on its way into buffer 0
+    int it = 0;                                        // items done by this workgroup (ticket slot = it & 1)
+    long long* trace_row = nullptr;
+    while (have) {
+        const int vb = p.lists == 8 ? 8 * t + list : t;                 // the item's index in the classic grid (= its trace row)
+        trace_row = (p.trace && vb < p.trace_rows) ? p.trace + 8 * (long)vb : nullptr;
+        if (trace_row && tid == 0) {
+            trace_row[0] = trace_row[1] = __builtin_amdgcn_s_memrealtime();
+            trace_row[4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+            trace_row[7] = (long long)blockIdx.x << 16 | (long long)it;
         }
-        if (!lean) {
+        set_lane_constants(gemm_opaque_tid());
+        if (it > 0) set_offsets(lane);
+        // every fragment register starts an item defined: a conditional read followed by an unconditional tie would otherwise keep the
+        // previous item's values alive across the epilogue (76 registers the epilogue does not have)
+        a0.clear(); a1.clear(); b0.clear(); b1.clear();
+        sc0 = sc1 = t4 = tb4 = ts4 = rs4 = zero4;
+        tbxy = tbzw = gemm_f32x2{0.f, 0.f};
+        // ---- prologue: tile 0 -> buffer 0 (unless the previous item's epilogue already sent it), group 0 of tile 0 into registers
+        if (!prefetched) {
 #pragma unroll
-            for (int m = 0; m < TM; ++m) gemm_epilogue_pair<EPI>(p, file, row_w + m * 32 + 4 * hh, col0 + wn * 64 + l31, acc[m][0], acc[m][1]);
+            for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
         }
-    }
-    if (TAIL) {
-        if (do_tail) {
-            smem[tid] = tail_acc;
-            __syncthreads();
-            if (tid < BN) {
-                const float s = (smem[tid] + smem[BN + tid]) + (smem[2 * BN + tid] + smem[3 * BN + tid]);
-                const int col = col0 + tid;
-                if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, file, p.tail_row, col, s);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        tail_acc = 0.f;
+        rowsum_acc = 0.f;
+        // row factors of the lean epilogue (visible after the prologue barrier; read only after the main loop)
+        if constexpr (EPI == EPI_STORE || EPI == EPI_UPDH) {
+#pragma unroll
+            for (int i = 0; i < BM / 256; ++i) {
+                const int lr = tid + 256 * i, row = min(row0 + lr, p.M - 1);
+                s_rowvec[lr] = p.ktailA ? p.ktailA[file * p.s_ktailA + row] : 0.f;
+                if (EPI == EPI_UPDH) {
+                    const float rd = 1.0f / (p.E2[file * p.sE2 + row] + p.alpha + p.eps);
+                    s_rowvec[BM + lr] = p.E1 ? p.E1[file * p.sE1 + row] * rd : rd;
+                }
             }
         }
-    }
-    if (B_KC) {
-        if (do_rowsum) {
-            float s = rowsum_acc;
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            const int j = tid >> 2;
-            if ((tid & 3) == 0 && (col0 + j) < p.N) p.rowsumB[file * p.s_rowsumB + col0 + j] = s;
+        if (tid == 0) {
+            s_arrivals = 0;
+            // the ticket of the NEXT item, taken now: its round trip is hidden by this item, and the epilogue can already fetch for it
+            if (persistent) s_ticket[it & 1] = p.wpl + (int)__hip_atomic_fetch_add(p.tickets + list, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
-    if (p.trace) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-    }
-}
+        read_group0(lds0);
+        wait_group0();
 
-// One launch of the LDS-DMA tile over the files [a.file0, a.file0 + a.batch)
-template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM>
-static int gccnmf_launch_gemm_dma_tm(GemmArgs a, hipStream_t stream) {
-    a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
-    a.tiles_n = gccnmf_ceil_div(a.N, 64);
-    const int tiles = a.tiles_m * a.tiles_n;
-    int grid;
-    if (a.xcd_affine && a.batch >= 8) {
-#ifdef GEMM_XCD_FILE_GRANULAR
-        a.xcd_affine = 1;
-        grid = 8 * gccnmf_ceil_div(a.batch, 8) * tiles;
-#else
-        a.xcd_affine = gccnmf_ceil_div(a.batch * tiles, 8);     // tiles per XCD
-        grid = 8 * a.xcd_affine;
+        if constexpr (NARROW) {
+            if (nw == 1) main_loop(std::integral_constant<int, 1>{});
+            else main_loop(std::integral_constant<int, 2>{});
+        } else {
+            main_loop(std::integral_constant<int, 2>{});
+        }
+        __syncthreads();                      // the epilogues reuse the staging buffers
+        if (trace_row && tid == 0) trace_row[2] = __builtin_amdgcn_s_memrealtime();
+
+        // ---- the finished item's coordinates move aside; the next item's operands are set up (and requested) before the epilogue
+        const int e_file = file, e_row0 = row0, e_col0 = col0, e_nw = nw;
+        const bool e_active = wave_active, e_tail = do_tail, e_rowsum = do_rowsum;
+        have = false;
+        prefetched = false;
+        if (persistent) {
+            t = __builtin_amdgcn_readfirstlane(s_ticket[it & 1]);
+            have = take_item(t);
+            if (have && p.prefetch) {
+                set_offsets(gemm_opaque_tid() & 63);           // (computed again at the top of the next item: not kept across the epilogue)
+#pragma unroll
+                for (int i = 0; i < NPIECES; ++i) dma_piece(i, 0, 0);
+                prefetched = true;
+            }
+        }
+        float* const scratch = smem + SBUF;             // epilogue scratch: buffer 1 (buffer 0 may be receiving the next item's first tile)
+
+        if constexpr (EPI == EPI_UPDW) {
+            // launch_rht_update_w guarantees M % 128 == 0 and N % 64 == 0 (a second, generic variant in this kernel would
+            // double the live ranges of the accumulators and spill the main loop)
+            gemm_epilogue_update_w_full<TAIL>(p, e_file, e_col0, tid, wm, l31, hh, e_active, acc, tail_acc, rowsum_acc, scratch);
+        } else {
+            if (e_active) {
+                const int row_w = e_row0 + wm * RW;                           // wave-uniform
+                bool lean = false;
+                if constexpr (EPI == EPI_STORE || EPI == EPI_DIV || EPI == EPI_UPDH) {
+                    lean = row_w + RW <= p.M;                               // all tile pairs of the wave have all their rows
+                    if (lean) {
+                        GemmEpiloguePair<EPI, BM> e0, e1;
+                        const int ca = e_col0 + l31, tr = wm * RW;
+                        const bool oka = ca < p.N, okb = (!NARROW || e_nw == 2) && ca + 32 < p.N;
+                        const long cb = 4L * p.ldc * (p.M + (TAIL ? 1 : 0));
+                        float ba = 0.f, bb = 0.f;
+                        e0.load(p, e_file, row_w, hh, ca, cb);
+                        e1.load(p, e_file, row_w + 32, hh, ca, cb);
+                        if (EPI != EPI_DIV && p.ktailA) {
+                            ba = p.ktailB[e_file * p.s_ktailB + min(ca, p.N - 1)];
+                            bb = p.ktailB[e_file * p.s_ktailB + min(ca + 32, p.N - 1)];
+                        }
+                        e0.finish(p, e_file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
+                        if (trace_row && tid == 0) trace_row[5] = __builtin_amdgcn_s_memrealtime();
+                        e0.load(p, e_file, row_w + 64, hh, ca, cb);
+                        e1.finish(p, e_file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1], oka, okb, cb);
+                        e1.load(p, e_file, row_w + 96, hh, ca, cb);
+                        e0.finish(p, e_file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
+                        e1.finish(p, e_file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
+                        if (trace_row && tid == 0) trace_row[6] = __builtin_amdgcn_s_memrealtime();
+                    }
+                }
+                if (!lean) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        gemm_epilogue_pair<EPI>(p, e_file, row_w + m * 32 + 4 * hh, e_col0 + wn * 64 + l31, acc[m][0], acc[m][1], !NARROW || e_nw == 2);
+                }
+            }
+            if (TAIL) {
+                if (e_tail) {
+                    scratch[tid] = tail_acc;
+                    __syncthreads();
+                    if (tid < (NARROW && e_nw == 1 ? 32 : BN)) {
+                        const float s = (scratch[tid] + scratch[BN + tid]) + (scratch[2 * BN + tid] + scratch[3 * BN + tid]);
+                        const int col = e_col0 + tid;
+                        if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, e_file, p.tail_row, col, s);
+                    }
+                }
+            }
+            if (B_KC) {
+                if (e_rowsum) {
+                    float s = rowsum_acc;
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    const int j = tid >> 2;
+                    if ((tid & 3) == 0 && (e_col0 + j) < p.N && (!NARROW || e_nw == 2 || j < 32)) p.rowsumB[e_file * p.s_rowsumB + e_col0 + j] = s;
+                }
+            }
+        }
+        if (trace_row) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (also waits for a prefetched first tile: timeline builds only)
+            __syncthreads();
+            if (tid == 0) trace_row[3] = __builtin_amdgcn_s_memrealtime();
+        }
+        ++it;
+        if (have) __syncthreads();            // s_rowvec, the scratch and s_arrivals are rewritten for the next item
+    }
+#ifdef GEMM_DMA_PROBE
+    if (p.trace && lane == 0 && (long)p.trace_grid + 4L * blockIdx.x + 4 <= p.trace_rows) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) p.trace[8 * ((long)p.trace_grid + blockIdx.x * 4 + wave) + i] = (long long)probe[i];
+        p.trace[8 * ((long)p.trace_grid + blockIdx.x * 4 + wave) + 7] = it;
+    }
 #endif
-    } else {
-        a.xcd_affine = 0;
-        grid = a.batch * tiles;
+    if (persistent && tid == 0) {
+        // the last workgroup to leave zeroes the counters: every other workgroup has taken its last ticket before it counted itself out
+        const unsigned gone = __hip_atomic_fetch_add(p.tickets + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(p.tickets + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    a.trace = (gccnmf_trace_buf && 5 * grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;   // timeline + 4 per-wave probe rows
-    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, TM>), dim3(grid), dim3(256), 0, stream, a);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
 }
 
-// A launch is whole rounds of 512 workgroups (two per CU) plus a partial one, and a partial round costs 0.135 ms however few
-// workgroups it holds (a workgroup alone on its CU: profiles/r02k_files_sweep.txt).  When that pays, the files the partial round
-// would take run as a second launch of HALF-HEIGHT tiles instead: twice the workgroups at half the length (80 files: 3 rounds + 64
-// tiles -> 76 files + 4 files as 160 half tiles, one per CU for a third of the time); a launch of less than one round may run
-// entirely on half-height tiles (16 files: 640 of them, three per CU).  Whole files only,
-// same k order per output element, so a file's bits do not depend on which launch it rides in.  Tuning key 9 (default on).
-extern int gccnmf_tune_tail_split;
+// ---- host side: the plan of a launch -----------------------------------------------------------------------------------------
+// How many wide tiles at the end of every list run as two narrow halves (GemmArgs.split): chosen by a list-scheduling model of ONE
+// list on its XCD -- 32 CUs x 2 workgroup slots taking items in order; an item advances at 1 / 250 of a wide tile per microsecond
+// beside a neighbour on its CU and at 1 / 135 alone (profiles/r02k_files_sweep.txt: a paired round of full tiles 0.25 ms, a workgroup
+// alone on its CU 0.135 ms at Kd = 1024; everything scales alike with Kd), a narrow item is GEMM_DMA_NARROW_COST of a wide one.
+// Results are cached per (wide, ragged) list length.
+#ifndef GEMM_DMA_NARROW_COST
+#define GEMM_DMA_NARROW_COST 0.56
+#endif
+extern int gccnmf_tune_tail_split;      // key 9
+extern int gccnmf_tune_persistent;      // key 18
+extern int gccnmf_tune_prefetch;        // key 19
+extern int gccnmf_tune_narrow_cost;     // key 20: cost of a narrow item in percent of a wide one (0 = GEMM_DMA_NARROW_COST)
+unsigned* gccnmf_ticket_block(hipStream_t stream);
+
+static double gemm_dma_makespan(int wide, int halves, int ragged, double narrow) {
+    constexpr int CUS = 32;
+    const double rp = 1.0 / 250.0, ra = 1.0 / 135.0;
+    double left[CUS][2];
+    bool busy[CUS][2];
+    for (int c = 0; c < CUS; ++c) busy[c][0] = busy[c][1] = false;
+    int next = 0;
+    const int total = wide + halves + ragged;
+    auto cost = [&](int i) { return i < wide ? 1.0 : narrow; };
+    auto fill = [&]() {
+        for (int s = 0; s < 2 && next < total; ++s)
+            for (int c = 0; c < CUS && next < total; ++c)
+                if (!busy[c][s]) {
+                    busy[c][s] = true;
+                    left[c][s] = cost(next++);
+                }
+    };
+    double t = 0.0;
+    fill();
+    for (;;) {
+        double dt = -1.0;
+        for (int c = 0; c < CUS; ++c) {
+            const int nb = (busy[c][0] ? 1 : 0) + (busy[c][1] ? 1 : 0);
+            if (!nb) continue;
+            const double r = nb == 2 ? rp : ra;
+            for (int s = 0; s < 2; ++s)
+                if (busy[c][s] && (dt < 0.0 || left[c][s] / r < dt)) dt = left[c][s] / r;
+        }
+        if (dt < 0.0) return t;
+        for (int c = 0; c < CUS; ++c) {
+            const int nb = (busy[c][0] ? 1 : 0) + (busy[c][1] ? 1 : 0);
+            if (!nb) continue;
+            const double r = nb == 2 ? rp : ra;
+            for (int s = 0; s < 2; ++s)
+                if (busy[c][s]) {
+                    left[c][s] -= dt * r;
+                    if (left[c][s] < 1e-9) busy[c][s] = false;
+                }
+        }
+        t += dt;
+        fill();
+    }
+}
+
+static int gemm_dma_plan_split(int cw, int cr) {
+    if (cw < 1) return 0;
+    static std::mutex mu;
+    static int cache_key[64][3], cache_val[64], cached = 0;
+    const int pct = gccnmf_tune_narrow_cost;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < cached; ++i)
+        if (cache_key[i][0] == cw && cache_key[i][1] == cr && cache_key[i][2] == pct) return cache_val[i];
+    const double narrow = pct > 0 ? pct / 100.0 : GEMM_DMA_NARROW_COST;
+    int best = 0;
+    double best_t = gemm_dma_makespan(cw, 0, cr, narrow);
+    const int smax = cw < 64 ? cw : 64;
+    for (int s = 2; s <= smax; s += 2) {
+        const double ts = gemm_dma_makespan(cw - s, 2 * s, cr, narrow);
+        if (ts < best_t * 0.985) {          // a split has to buy at least 1.5 %
+            best_t = ts;
+            best = s;
+        }
+    }
+    const int slot = cached < 64 ? cached++ : 63;
+    cache_key[slot][0] = cw; cache_key[slot][1] = cr; cache_key[slot][2] = pct;
+    cache_val[slot] = best;
+    return best;
+}
+
+// The plan of one launch over the files [a.file0, a.file0 + a.batch): tile counts, the per-XCD lists, how many tiles are split.
+// narrow_capable: the kernel instantiation carries the 512 x 32 loop.  Returns the size of the classic grid (items of the longest list x lists).
+static int gemm_dma_plan(GemmArgs& a, bool narrow_capable) {
+    a.tiles_m = gccnmf_ceil_div(a.M, 512);
+    a.tiles_n = gccnmf_ceil_div(a.N, 64);
+    const int policy = gccnmf_tune_tail_split;                          // 0: wide tiles only | 1: by the model | 2: every tile as two narrow halves
+    const bool narrow_ok = narrow_capable && policy != 0;
+    a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;
+    a.wide_n = a.tiles_n - a.rag;
+    a.lists = (a.xcd_affine && a.batch >= 8) ? 8 : 1;
+    const long wide = (long)a.batch * a.tiles_m * a.wide_n, ragged = (long)a.batch * a.rag * a.tiles_m;
+    if (wide + ragged > (1L << 28)) return -1;
+    a.cw = (int)((wide + a.lists - 1) / a.lists);
+    a.cr = (int)((ragged + a.lists - 1) / a.lists);
+    a.split = 0;
+    if (narrow_ok) {
+        if (policy == 2) a.split = a.cw;
+        else if (!a.concurrent && a.lists == 8 && !gccnmf_trace_buf) a.split = gemm_dma_plan_split(a.cw, a.cr);
+    }
+    return a.lists * (a.cw + a.split + a.cr);
+}
+
+// One launch of the LDS-DMA tile over the files [a.file0, a.file0 + a.batch).
 template <bool A_KC, bool B_KC, int EPI, bool TAIL>
 static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
     if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
+    constexpr bool NARROW = (EPI == EPI_DIV || EPI == EPI_UPDH || EPI == EPI_STORE);
     a.ablate = gccnmf_tune_ablate;
     a.exact_div = gccnmf_tune_exact_div;
-    if constexpr (EPI != EPI_UPDW) {
-        const long tpf = (long)gccnmf_ceil_div(a.M, 512) * gccnmf_ceil_div(a.N, 64);     // throughput tiles per file
-        const long total = tpf * a.batch, rounds = total / 512;
-        // Decided by a cost model in units of one paired round of full tiles = 250 (measured at Kd = 1024: 0.25 ms; everything scales
-        // with Kd alike): a partial round of <= 256 full tiles costs 135 (one workgroup alone per CU), a larger one a whole round;
-        // half-height workgroups (130-170 VGPRs, 43 KB of LDS: three per CU, 768 per round) cost 85 up to one per CU, 135 up to two,
-        // 190 for three; a second launch costs 10 (profiles/r03g_files_sweep.txt, r03k_files_sweep.txt).
-        if (gccnmf_tune_tail_split == 2 && a.M > 256)                 // experiment: every tile half-height (three workgroups per CU)
-            return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
-        if (gccnmf_tune_tail_split && !gccnmf_trace_buf && !a.concurrent && a.M > 256) {
-            // three forms, priced for a launch that has the chip to itself: all full tiles | whole rounds of full tiles + the rest
-            // of the files half-height | everything half-height (768 per round: 32 files 0.389 -> 0.330 ms, 16 files 0.249 -> 0.192)
-            auto full_cost = [](long tiles) { const long r = tiles % 512; return (tiles / 512) * 250 + (r == 0 ? 0 : r <= 256 ? 135 : 250); };
-            auto half_cost = [](long halves) {
-                const long r = halves % 768;
-                return (halves / 768) * 190 + (r == 0 ? 0 : r <= 256 ? 85 : r <= 512 ? 135 : 190);
-            };
-            const long plain = full_cost(total), all_half = half_cost(2 * total);
-            long split = 1L << 40;
-            const int head = (int)(rounds * 512 / tpf);              // whole files that fit the whole rounds
-            const int rest = a.batch - head;
-            if (rounds >= 1 && head >= 8 && rest >= 1 && 2 * rest * tpf <= 768) split = full_cost(head * tpf) + half_cost(2 * rest * tpf) + 10;
-            if (all_half < plain && all_half <= split) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
-            if (split < plain) {
-                GemmArgs h = a, t = a;
-                h.batch = head;
-                t.batch = rest;
-                t.file0 = a.file0 + head;
-                int rc = gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(h, stream);
-                if (rc) return rc;
-                return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(t, stream);
-            }
+    const int classic_grid = gemm_dma_plan(a, NARROW);
+    if (classic_grid < 1) return GCCNMF_ERR_ARG;
+    a.trace = gccnmf_trace_buf;
+    a.trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks : 0;
+    a.trace_grid = classic_grid;
+    a.tickets = nullptr;
+    a.prefetch = gccnmf_tune_prefetch;
+    a.wpl = 0;
+    int grid = classic_grid;
+    if (gccnmf_tune_persistent && classic_grid > 512) {
+        a.tickets = gccnmf_ticket_block(stream);
+        if (a.tickets) {
+            grid = 512;
+            a.wpl = 512 / a.lists;
         }
     }
-    return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(a, stream);
+    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, NARROW>), dim3(grid), dim3(256), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
 }

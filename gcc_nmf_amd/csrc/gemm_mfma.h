@@ -92,6 +92,14 @@ struct GemmArgs {
     float alpha, eps;
     int T, Tp, Fp, ldv;        // EPI_PHASE geometry
     long long* trace;          // debug: per-workgroup timeline, 8 x int64 per block (gccnmf_debug_set_trace)
+    // LDS-DMA throughput tile (gemm_dma.h): the launch's work lists, set by gccnmf_launch_gemm_dma
+    int lists;                 // 8 = one ordered item list per XCD (blockIdx & 7), 1 = one list
+    int cw, cr;                // wide tiles / ragged narrow tiles per list (chunks of the file-major lists)
+    int split;                 // the last `split` wide tiles of every list run as two narrow (512 x 32) halves
+    int rag, wide_n;           // rag = 1: the last column tile of a file is a narrow item; wide_n = tiles_n - rag
+    int wpl, prefetch;         // persistent grid: resident workgroups per list; 1 = the next item's first k-tile is requested before the epilogue
+    unsigned* tickets;         // persistent grid: [0..7] next-item counters per list, [8] workgroups gone; nullptr = classic grid
+    int trace_rows, trace_grid;   // rows of the trace buffer; items of the classic grid (the per-wave probe rows start behind them)
 };
 
 template <int EPI>
@@ -144,9 +152,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, int file, int r
 // be reordered by the compiler) and cost as much as the whole k-loop.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, int row_base, int col_a, const f32x16& acc_in_a,
-                                                   const f32x16& acc_in_b) {
+                                                   const f32x16& acc_in_b, bool allow_b = true) {
     const int col_b = col_a + 32;
-    const bool ok_a = gemm_col_valid<EPI>(p, col_a), ok_b = gemm_col_valid<EPI>(p, col_b);
+    const bool ok_a = gemm_col_valid<EPI>(p, col_a), ok_b = allow_b && gemm_col_valid<EPI>(p, col_b);      // allow_b = false: a narrow (32-column) item
     // (the accumulators are never written here: a second code path that modifies them next to the lean epilogues of
     // gemm_dma.h doubles their live ranges and spills)
     float acc_a[16], acc_b[16];

@@ -20,7 +20,11 @@ int gccnmf_tune_ablate = 0;
 #define GCCNMF_SHARED_STREAMS 4
 #define GCCNMF_DIRECT_MAX_BATCH 16   // workspaces of at most this many files carry the transposed copies of the direct path
 int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
-int gccnmf_tune_tail_split = 1;       // key 9: the files of a launch's partial last round run as half-height tiles (gemm_dma.h)
+int gccnmf_tune_tail_split = 1;       // key 9: 1 (default) = a throughput-tile launch may hold narrow (512 x 32) items: a file's ragged last column tile, and the
+                                      // end of each XCD's list split by the list-scheduling model (gemm_dma.h); 0 = wide tiles only; 2 = every tile as two halves
+int gccnmf_tune_persistent = 1;       // key 18: 1 (default) = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
+int gccnmf_tune_prefetch = 1;         // key 19: 1 (default) = a resident workgroup requests its next item's first k-tile before the current item's epilogue
+int gccnmf_tune_narrow_cost = 0;      // key 20: cost of a narrow item in the split model, percent of a wide one (0 = built-in)
 int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
@@ -64,6 +68,18 @@ int gccnmf_set_tuning(int key, int value) {
     }
     if (key == 9 && value >= 0 && value <= 2) {
         gccnmf_tune_tail_split = value;
+        return GCCNMF_OK;
+    }
+    if (key == 18 && (value == 0 || value == 1)) {
+        gccnmf_tune_persistent = value;
+        return GCCNMF_OK;
+    }
+    if (key == 19 && (value == 0 || value == 1)) {
+        gccnmf_tune_prefetch = value;
+        return GCCNMF_OK;
+    }
+    if (key == 20 && value >= 0 && value <= 100) {
+        gccnmf_tune_narrow_cost = value;
         return GCCNMF_OK;
     }
     if (key == 8 && value >= 1 && value <= GCCNMF_SHARED_STREAMS) {
@@ -113,6 +129,43 @@ int gccnmf_set_tuning(int key, int value) {
     return GCCNMF_ERR_ARG;
 }
 
+}  // extern "C"
+
+// Ticket blocks of the persistent throughput-tile launches (gemm_dma.h): 16 counters per (device, stream), zero between launches (the last
+// workgroup of a launch resets them).  Launches on one stream are serialised, so a stream's launches share a block; every stream has its own.
+// nullptr (pool exhausted, allocation refused -- e.g. inside a stream capture) = the launch falls back to the classic grid.
+unsigned* gccnmf_ticket_block(hipStream_t stream) {
+    constexpr int MAX_DEV = 16, PER_DEV = 128;
+    struct Entry { hipStream_t s; };
+    static std::mutex mu;
+    static unsigned* pool[MAX_DEV] = {};
+    static Entry entries[MAX_DEV][PER_DEV];
+    static int used[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < used[dev]; ++i)
+        if (entries[dev][i].s == stream) return pool[dev] + 16 * i;
+    if (used[dev] == PER_DEV) return nullptr;
+    if (!pool[dev]) {
+        static const unsigned zeros[16 * PER_DEV] = {};
+        unsigned* p = nullptr;
+        if (hipMalloc((void**)&p, sizeof(zeros)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemcpy(p, zeros, sizeof(zeros), hipMemcpyHostToDevice) != hipSuccess) {      // blocking: the counters are zero before any launch reads them
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        pool[dev] = p;
+    }
+    entries[dev][used[dev]].s = stream;
+    return pool[dev] + 16 * used[dev]++;
+}
+
+extern "C" {
 int gccnmf_debug_set_trace(long long* buf, int blocks) {
     gccnmf_trace_buf = buf;
     gccnmf_trace_blocks = buf ? blocks : 0;
@@ -1246,6 +1299,28 @@ int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) 
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items) {
+    if (M < 1 || N < 1 || batch < 1 || !plan || (max_items > 0 && !items)) return -1;
+    GemmArgs a = {};
+    a.M = M; a.N = N; a.batch = batch; a.xcd_affine = xcd_affine; a.concurrent = concurrent;
+    const int grid = gemm_dma_plan(a, narrow_capable != 0);
+    if (grid < 1) return -1;
+    const int fields[8] = {a.lists, a.cw, a.cr, a.split, a.rag, a.tiles_m, a.tiles_n, grid};
+    for (int i = 0; i < 8; ++i) plan[i] = fields[i];
+    int n = 0;
+    for (int list = 0; list < a.lists; ++list)
+        for (int t = 0;; ++t) {
+            int file, tm, col0, nw;
+            if (!gemm_dma_item(a, list, t, file, tm, col0, nw)) break;      // the same decode the kernel runs
+            if (n < max_items) {
+                int* it = items + 6 * n;
+                it[0] = list; it[1] = t; it[2] = file; it[3] = tm; it[4] = col0; it[5] = nw;
+            }
+            ++n;
+        }
+    return n;
 }
 
 int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc,

@@ -57,9 +57,13 @@ int gccnmf_version(void);
  * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
  * small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
  * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
- * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
- * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout
- * (bitwise the same results in every form); 0 = always full tiles; 2 = always half-height (experiments).
+ * key 9: 1 (default) = a throughput-tile launch may hold NARROW (512 x 32) items next to its 512 x 64 tiles: a file's ragged last
+ * column tile when at most 32 of its columns exist, and the last tiles of each XCD's list split in two by a list-scheduling model of
+ * the launch (it has to have the chip to itself) -- same k order per element, bitwise the same results in every form; 0 = wide tiles
+ * only; 2 = every tile as two narrow halves (tests).  key 18: 1 (default) = launches of more than 512 items run as 512 RESIDENT
+ * workgroups that pull items through a ticket counter (work-conserving; the classic grid otherwise).  key 19: 1 (default) = a resident
+ * workgroup requests its next item's first k-tile before the current item's epilogue.  key 20: cost of a narrow item in the split
+ * model in percent of a wide one (0 = built-in).
  * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..16, default 4).
@@ -376,6 +380,13 @@ typedef struct gccnmf_direct_gemm {
     long long* trace;          /* library-filled: per-workgroup timeline while gccnmf_debug_set_trace is armed */
 } gccnmf_direct_gemm;
 int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream);
+
+/* Diagnostics (tests only, no device needed): the work lists a throughput-tile launch (csrc/gemm_dma.h) would use for an M x N output
+ * over `batch` files under the current tuning -- the SAME tile decode the kernel runs, executed on the host.
+ *   plan  [8]: lists, wide tiles per list, ragged narrow tiles per list, split, rag, tiles_m, tiles_n, items of the classic grid
+ *   items [max_items][6]: list, ticket, file, row tile, first column, column blocks (2 = 512 x 64, 1 = a narrow 512 x 32 item)
+ * Returns the number of items (all lists), -1 on bad arguments. */
+int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items);
 
 /* Diagnostics (tests only): run one MFMA GEMM configuration in isolation.
  * layout bits: 1 = A reduction-contiguous, 2 = B reduction-contiguous, 4 = VALU tail row, 8 = <1,4> wave grid,
