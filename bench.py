@@ -48,6 +48,7 @@ def parse():
                         'whole batch, the configuration the roofline kernel is timed in')
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
+    p.add_argument('--skip-config-lines', action='store_true', help='no sub-records of the other BASELINE configurations (K = 128 batch, K sweep, 200 iterations, shared dictionary, streaming, big matrix)')
     p.add_argument('--skip-extras', action='store_true', help='sweeps: only the timed steps and the roofline kernel (no host-to-host, single-file, drop-in, CPU legs)')
     p.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='gccnmf_set_tuning(KEY, VALUE) before running (A/B experiments)')
     p.add_argument('--h-updates', type=int, default=2, help='streaming mode: KL-NMF coefficient updates per frame (W fixed)')
@@ -194,21 +195,17 @@ def time_sharded_mode(a, world, rank, local_rank, barrier, ranks_seen, backend):
         dist.destroy_process_group()
 
 
-def streaming_mode(a):
-    """BASELINE config 5: RT-GCC-NMF, pre-trained-size K = 1024 dictionary, 512-pt ASYMMETRIC analysis / synthesis windows (synthesis
-    window 128 samples), hop = block = 64 samples (4 ms at 16 kHz), per-frame coefficient inference (numHUpdates KL-NMF H updates with
-    W fixed) + mask, 64 TDOAs, online localisation.  Reports p50 / p99 of the fused device call per block (host block in -> host block
-    out, i.e. including both PCIe copies and the stream sync), the real-time factor, and the device-resident rate; the same numbers
-    for the reference's own configuration of that path (symmetric sqrt-hamming window, no coefficient inference) ride along."""
+def streaming_measure(K, n_h, seconds=10.0):
+    """(low-latency configuration, the reference's own configuration) of BASELINE config 5, each a dict of per-block latencies; see
+    streaming_mode."""
     import torch
     from gcc_nmf_amd.realtime import GCCNMFProcessor, StreamingGCCNMF, asymmetricWindows
     from gcc_nmf_amd.synthetic import synthetic_mixture
-    torch.cuda.set_device(0)
-    ws, hop, B, K, D, sr = 512, 64, 64, a.dictionary_size, 64, 16000
+    ws, hop, B, D, sr = 512, 64, 64, 64, 16000
     rng = np.random.RandomState(0)
     W = rng.rand(ws // 2 + 1, K).astype(np.float32) + 0.02
     W /= np.linalg.norm(W, axis=0)
-    x = synthetic_mixture(0, numSamples=sr * 10, delays=(-3, 1, 4))
+    x = synthetic_mixture(0, numSamples=int(sr * seconds), delays=(-3, 1, 4))
     n_blocks = x.shape[1] // B
     block_ms = 1e3 * B / sr
 
@@ -239,9 +236,20 @@ def streaming_mode(a):
                 'device_resident_real_time_factor': dev_ms / block_ms, 'tracked_tdoa_index': p.targetTDOAIndex,
                 'output_finite': bool(np.isfinite(y).all())}
 
-    n_h = a.h_updates
-    low = measure(n_h, asymmetricWindows(ws, 2 * hop), 1)
-    ref = measure(0, None, 2)
+    return measure(n_h, asymmetricWindows(ws, 2 * hop), 1), measure(0, None, 2), dict(ws=ws, hop=hop, B=B, D=D, sr=sr, block_ms=block_ms)
+
+
+def streaming_mode(a):
+    """BASELINE config 5: RT-GCC-NMF, pre-trained-size K = 1024 dictionary, 512-pt ASYMMETRIC analysis / synthesis windows (synthesis
+    window 128 samples), hop = block = 64 samples (4 ms at 16 kHz), per-frame coefficient inference (numHUpdates KL-NMF H updates with
+    W fixed) + mask, 64 TDOAs, online localisation.  Reports p50 / p99 of the fused device call per block (host block in -> host block
+    out, i.e. including both PCIe copies and the stream sync), the real-time factor, and the device-resident rate; the same numbers
+    for the reference's own configuration of that path (symmetric sqrt-hamming window, no coefficient inference) ride along."""
+    import torch
+    torch.cuda.set_device(0)
+    K, n_h = a.dictionary_size, a.h_updates
+    low, ref, c = streaming_measure(K, n_h)
+    ws, hop, B, sr, block_ms = c['ws'], c['hop'], c['B'], c['sr'], c['block_ms']
     print(json.dumps({
         'metric': 'RT-GCC-NMF p50 per-frame latency (512-pt asymmetric window, hop 64, K=%d, %d H updates per frame)' % (K, n_h),
         'value': low['p50_ms'], 'unit': 'ms', 'n_gpus': 1, 'steps': low['blocks'], 'warmup': 50, 'ms_per_step': low['mean_ms'],
@@ -258,6 +266,111 @@ def streaming_mode(a):
         'output_finite': low['output_finite'],
         'reference_configuration': dict(ref, note='the reference processor as it is: symmetric sqrt-hamming 512-pt window for analysis and '
                                                   'synthesis, no coefficient inference (its numHUpdates is unused), output two blocks late')}))
+
+
+def config_lines(a, e, xs, sr, n, local_rank):
+    """BASELINE.json's OTHER configurations and the dictionary sizes between the two tuned points, each timed LIVE on rank 0 after the
+    timed region of the default line (until round 4 these rested on builder-kept files under profiles/ only).  Compact
+    sub-records; every engine is released before the next one is built.  Whole call: about a minute."""
+    import torch
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    B, dev = e.batch, 'cuda:%d' % local_rank
+    res = {}
+
+    def timed_runs(eng, steps):
+        eng.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            eng.run()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / steps
+
+    def batch_line(K, hop, steps, iters=100):
+        eng = GCCNMFEngine(n, sampleRate=sr, windowSize=1024, hopSize=hop, numTDOAs=128, microphoneSeparationInMetres=1.0, numTargets=3,
+                           dictionarySize=K, numIterations=iters, batch=B, device=dev)
+        eng.upload(xs)
+        dt = timed_runs(eng, steps)
+        g = eng.g
+        iter_ms, k3_ms = kernel_timings(eng, iterations=5, launches=10)
+        gemm_flop = 2.0 * g.F * g.K * g.N * B
+        plan = int(eng.lib.gccnmf_klnmf_plan(g.F, g.N, g.K, eng.batch, eng.klnmf_flags))
+        slabs = bool(plan & 4)
+        rec = {'files': B, 'hop': hop, 'dictionary_size': K, 'nmf_iterations': iters, 'frames_per_s': B * g.T / dt, 'ms_per_step': 1e3 * dt,
+               'nmf_file_groups': eng.nmf_groups, 'klnmf_plan': plan,
+               'iteration_ms_one_stream': float(iter_ms), 'iteration_frac': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+               'roofline': {'bound': 'mfma', 'kernel': 'gccnmf_whdiv_rht_kernel (K3 + K4a, one launch)' if slabs else 'gccnmf_gemm_dma_kernel (K3)',
+                            'achieved': (2 if slabs else 1) * gemm_flop / (k3_ms * 1e-3) / 1e12, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': (2 if slabs else 1) * gemm_flop / (k3_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 'avg_launch_ms': float(k3_ms)},
+               'tdoa_indexes_as_expected': bool((eng.get_tdoa_indexes() == np.array([27, 59, 91])).all()) if (n, hop) == (160000, 256) else None}
+        del eng
+        torch.cuda.empty_cache()
+        return rec
+
+    # config 1's dictionary (the reference driver's K = 128, runGCCNMF.py:41) at batch scale, at BASELINE's hop and at the driver's own (:60)
+    res['k128_batch'] = {'hop256': batch_line(128, 256, 5), 'hop128': batch_line(128, 128, 3),
+                         'what': 'BASELINE config 1 parameters (K = 128, 100 iterations) on config 3\'s batch; hop 128 = runGCCNMF.py:60'}
+    # realtime/config.py:71 trains [64, 128, 256, 512, 1024]: the sizes between the tuned points
+    res['k_sweep'] = {str(K): batch_line(K, 256, 2) for K in (64, 256, 512)}
+    # config 3 as written: 200 iterations
+    e.iters = 200
+    dt = timed_runs(e, 2)
+    e.iters = a.iterations
+    res['it200'] = {'files': B, 'nmf_iterations': 200, 'frames_per_s': B * e.g.T / dt, 'ms_per_step': 1e3 * dt, 'what': 'BASELINE config 3 as written'}
+    # config 4's per-rank shape: one dictionary for the rank's files (no exchange at one rank)
+    from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
+    g = e.g
+    e.stft()
+    W0, H0 = shared_initial_factors(g.F, [g.N] * B, g.K, list(range(B)), mode='per_file')
+    local = HipSharedNMF.from_device(e.V, g.F, g.N, W0, H0)
+
+    def shared_step():
+        local.reset()
+        train_shared_dictionary(local, a.iterations)
+    shared_step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(2):
+        shared_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / 2
+    res['shared_dictionary_n1'] = {'files': B, 'frames_per_s': B * g.T / dt, 'ms_per_step': 1e3 * dt, 'collective': local.collective,
+                                   'what': 'BASELINE config 4 on one rank: one dictionary for %d files, the iteration loop in C' % B}
+    del local, W0, H0
+    torch.cuda.empty_cache()
+    # config 5
+    low, ref, c = streaming_measure(a.dictionary_size, a.h_updates, seconds=4.0)
+    res['streaming'] = {'p50_ms': low['p50_ms'], 'p99_ms': low['p99_ms'], 'real_time_factor_p50': low['real_time_factor_p50'],
+                        'device_resident_ms_per_block': low['device_resident_ms_per_block'], 'blocks': low['blocks'],
+                        'reference_configuration_p50_ms': ref['p50_ms'], 'block_duration_ms': c['block_ms'],
+                        'what': 'BASELINE config 5: 512-pt asymmetric windows, hop 64, K = %d, %d H updates per frame, host block in -> out' % (a.dictionary_size, a.h_updates)}
+    # the dictionary pre-training call (gccNMFPretraining.py:79-80): ONE matrix of 80 000 columns through the column-block path
+    from gcc_nmf_amd.distributed import HipSharedColumns
+    from gcc_nmf_amd.engine import Geometry
+    N, K, iters, F = 80000, 1024, 10, 513
+    gg = Geometry(F, 1, K)
+    gen = torch.Generator(device=dev).manual_seed(80000)
+    Vd = torch.zeros((gg.Fp, N), device=dev)
+    Wd = torch.zeros((gg.Fp, gg.Kp), device=dev)
+    Hd = torch.zeros((gg.Kp, N), device=dev)
+    Vd[:F] = torch.rand((F, N), device=dev, generator=gen) + 0.01
+    Wd[:F, :K] = torch.rand((F, K), device=dev, generator=gen) + 1e-16
+    Hd[:K] = torch.rand((K, N), device=dev, generator=gen) + 1e-16
+    run = HipSharedColumns(Vd, Hd, Wd, F, N, K)
+    run.run(2, collective=False)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    run.run(iters, collective=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1)
+    res['big_matrix_n80000'] = {'N': N, 'K': K, 'iterations': iters, 'ms_per_iteration': ms / iters,
+                                'frac_of_f32_mfma_peak': 4 * 2.0 * F * K * N * iters / ms / 1e9 / F32_MFMA_PEAK_TFLOPS,
+                                'what': 'performKLNMF on ONE (513, 80000) matrix: in-place column blocks on the batched kernels (device-resident part)'}
+    del run, Vd, Wd, Hd
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(n):
@@ -479,6 +592,11 @@ def main():
                                          'frames': e2.g.T, 'ms_per_file': 1e3 * dt2, 'frames_per_s': e2.g.T / dt2,
                                          'dropin_performKLNMF_ms': 1e3 * (time.perf_counter() - t1)}
         del e2
+
+    if rank == 0 and world == 1 and not a.skip_extras and not a.skip_config_lines and (K, iters, a.hop, a.seconds) == (1024, 100, 256, 10.0):
+        t1 = time.perf_counter()
+        out.update(config_lines(a, e, xs, sr, n, local_rank))
+        out['config_lines_seconds'] = time.perf_counter() - t1
 
     if rank == 0 and world == 1 and not a.skip_cpu_baseline and not a.skip_extras:
         from oracle import gccnmf_oracle as O                                # the checker, timed as the CPU baseline

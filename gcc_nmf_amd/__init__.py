@@ -11,12 +11,19 @@ package does not need a GPU; calling any hot-path function without the library o
 ``HipLibraryError`` -- there is no CPU fallback.
 """
 import os as _os
+import sys as _sys
 
 # Multi-process GPU work on this driver stack needs dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL (and any CUDA-tensor sharing
 # across processes) fails with `hipIpcGetMemHandle: invalid argument`.  The runtime reads it when HIP initialises, so it is set on
-# import -- before torch has touched a device in any ordinary program -- unless the user chose a value.  distributed.collective_hook
-# re-checks it where it matters.
-_os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# import -- before torch has touched a device in any ordinary program -- unless the user chose a value.  It is a PROCESS-wide switch
+# (every HIP user in the process sees it): GCCNMF_NO_IPC_ENV=1 keeps this package's hands off it.  If HIP was already running when the
+# package was imported the setting cannot take effect any more; distributed.collective_hook says so in its error messages.
+HIP_STARTED_BEFORE_IMPORT = bool('torch' in _sys.modules and getattr(_sys.modules['torch'], 'cuda', None) is not None and
+                                 _sys.modules['torch'].cuda.is_initialized())
+IPC_ENV_SET_BY_PACKAGE = False
+if _os.environ.get('GCCNMF_NO_IPC_ENV', '') in ('', '0') and 'HSA_ENABLE_IPC_MODE_LEGACY' not in _os.environ:
+    _os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    IPC_ENV_SET_BY_PACKAGE = True
 
 from ._hip import HipLibraryError, LIB_PATH   # noqa: F401,E402
 

@@ -468,7 +468,11 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
     const int wm = wave, wn = 0;
     int l31 = lane & 31, hh = lane >> 5;
+#ifdef GCCNMF_EXPERIMENTS
     const bool persistent = p.tickets != nullptr;
+#else
+    constexpr bool persistent = false;          // the resident-workgroup form is an experiment build (make EXPERIMENTS=1): measured slower, see LABBOOK.md
+#endif
     const int list = p.lists == 8 ? (int)(blockIdx.x & 7) : 0;
     int t = p.lists == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;            // first item: static (the counter starts behind the resident workgroups)
 
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 // alone on its CU 0.135 ms at Kd = 1024; everything scales alike with Kd), a narrow item is GEMM_DMA_NARROW_COST of a wide one.
 // Results are cached per (wide, ragged) list length.
 #ifndef GEMM_DMA_NARROW_COST
-#define GEMM_DMA_NARROW_COST 0.56
+#define GEMM_DMA_NARROW_COST 0.59      // measured: K1 over 64 files with every tile split (profiles/r05a_kbench_all_narrow.txt) 0.786 ms against 0.663
 #endif
 extern int gccnmf_tune_tail_split;      // key 9
 extern int gccnmf_tune_persistent;      // key 18
@@ -1090,6 +1094,7 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     a.prefetch = gccnmf_tune_prefetch;
     a.wpl = 0;
     int grid = classic_grid;
+#ifdef GCCNMF_EXPERIMENTS
     if (gccnmf_tune_persistent && classic_grid > 512) {
         a.tickets = gccnmf_ticket_block(stream);
         if (a.tickets) {
@@ -1097,6 +1102,7 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
             a.wpl = 512 / a.lists;
         }
     }
+#endif
     hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, NARROW>), dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;

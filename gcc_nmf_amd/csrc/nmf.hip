@@ -18,12 +18,13 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);
 
 int gccnmf_tune_ablate = 0;
 #define GCCNMF_SHARED_STREAMS 4
-#define GCCNMF_DIRECT_MAX_BATCH 16   // workspaces of at most this many files carry the transposed copies of the direct path
+#define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
+                                     // the ring / throughput kernels win anyway: 8 files 41.5 against 41.3 ms, 12 files 61.9 against 59.3)
 int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
 int gccnmf_tune_tail_split = 1;       // key 9: 1 (default) = a throughput-tile launch may hold narrow (512 x 32) items: a file's ragged last column tile, and the
                                       // end of each XCD's list split by the list-scheduling model (gemm_dma.h); 0 = wide tiles only; 2 = every tile as two halves
-int gccnmf_tune_persistent = 1;       // key 18: 1 (default) = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
-int gccnmf_tune_prefetch = 1;         // key 19: 1 (default) = a resident workgroup requests its next item's first k-tile before the current item's epilogue
+int gccnmf_tune_persistent = 0;       // key 18 (experiment builds only): 1 = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
+int gccnmf_tune_prefetch = 1;         // key 19 (experiment builds only): 1 = a resident workgroup requests its next item's first k-tile before the current item's epilogue
 int gccnmf_tune_narrow_cost = 0;      // key 20: cost of a narrow item in the split model, percent of a wide one (0 = built-in)
 int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)

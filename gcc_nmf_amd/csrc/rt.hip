@@ -615,6 +615,12 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
         GCCNMF_CHECK_LAUNCH();
     }
     const size_t lds_dft = sizeof(float2) * (2 * windowSize + 2);
+    if (!pow2 && lds_dft + 4096 > 64 * 1024) {
+        // windows above ~3800 samples: the table + frame image (+ the analysis kernel's 4 KB of static LDS) pass the 64 KB a launch gets by default
+        if (hipFuncSetAttribute((const void*)rt_frames_dft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dft) != hipSuccess ||
+            hipFuncSetAttribute((const void*)rt_synth_dft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dft) != hipSuccess)
+            return GCCNMF_ERR_LAUNCH;
+    }
     if (pow2) {
         hipLaunchKernelGGL(rt_frames_kernel, dim3(Tc), dim3(FFT_NT), lds, s, in_ring, ring, windowSize, logN, start0, start_step, Tc,
                            window, (const float2*)twiddle, (float2*)X, (float2*)C);

@@ -75,6 +75,10 @@ def _ipc_env_note():
     import os
     v = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
     if v == '0':
+        import gcc_nmf_amd
+        if gcc_nmf_amd.IPC_ENV_SET_BY_PACKAGE and gcc_nmf_amd.HIP_STARTED_BEFORE_IMPORT:
+            return ('HSA_ENABLE_IPC_MODE_LEGACY=0 was set by gcc_nmf_amd AFTER the HIP runtime had started in this process (torch touched a '
+                    'device before the import), so it has no effect: export it in the environment of the launcher instead')
         return ''
     return ('HSA_ENABLE_IPC_MODE_LEGACY is %s in this process (it must be 0 BEFORE the HIP runtime starts: the host driver only supports '
             'dmabuf IPC, RCCL otherwise fails with hipIpcGetMemHandle: invalid argument)' % ('unset' if v is None else repr(v)))
@@ -102,6 +106,15 @@ def _call_with_timeout(fn, seconds, what):
     if 'error' in box:
         raise box['error']
     return box['value']
+
+
+def _try_rccl_init(init, seconds, what):
+    """(ok, why): init() behind the time limit.  A timeout is NOT raised here: the caller still owes its peers the agreement all-reduce
+    (raising first would leave them waiting in it until torch's own timeout), so it comes back as (False, explanation)."""
+    try:
+        return bool(_call_with_timeout(init, seconds, what)), None
+    except _hip.HipLibraryError as e:
+        return False, str(e)
 
 
 def _rccl_comm(group, device):
@@ -135,13 +148,22 @@ def _rccl_comm(group, device):
         def init():
             with torch.cuda.device(device):
                 return lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
-        ok = _call_with_timeout(init, timeout, 'gccnmf_rccl_comm_init (rank %d of %d, device %s)' % (rank, world, device))
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        ok, why = _try_rccl_init(init, timeout, 'gccnmf_rccl_comm_init (rank %d of %d, device %s)' % (rank, world, device))
+        # one agreement for both questions: did EVERY rank get a communicator, and did NO rank give up on a timeout
+        flag = torch.tensor([1 if ok else 0, 0 if why else 1], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()):
+        agreed, nobody_timed_out = int(flag[0].item()), int(flag[1].item())
+        if agreed:
             comm = handle.value
-        elif ok:
-            lib.gccnmf_rccl_comm_destroy(handle)
+        else:
+            if ok:
+                lib.gccnmf_rccl_comm_destroy(handle)
+            import warnings
+            warnings.warn('gcc_nmf_amd: the library RCCL communicator could not be set up on every rank (%s); the shared-dictionary all-reduce '
+                          'goes through torch.distributed instead (GCCNMF_COLLECTIVE=torch semantics, same results)'
+                          % (why or 'gccnmf_rccl_comm_init failed on this or another rank'), RuntimeWarning)
+            if not nobody_timed_out:
+                return None              # a timeout somewhere: not cached on ANY rank, the next training tries RCCL again (all ranks alike)
     _rccl_comms[key] = (comm, world, rank)
     return comm
 

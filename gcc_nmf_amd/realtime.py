@@ -126,7 +126,8 @@ class GCCNMFProcessor(object):
         self.dTarget = part(4, 4)
         self.dTarget.copy_(torch.from_numpy(self._target_host))
         self._mirror_offs, self._mirror_sizes, self._mirror_host = offs, sizes, None
-        self._calls, self._target_seen, self._target_value, self._target_pin = 0, -1, float(self._target_host[0]), None
+        # _target_dirty: a device call ran with the online localisation on since the value was last known on the host
+        self._calls, self._target_dirty, self._target_value, self._target_pin = 0, False, float(self._target_host[0]), None
         self.dFramesIn, self.dFramesOut = z(2, Tc, self.windowSize), z(2, Tc, self.windowSize)
 
     @_on_device
@@ -134,27 +135,29 @@ class GCCNMFProcessor(object):
         """:272-275"""
         self._target_host = np.array([targetTDOAIndex, targetTDOAEpsilon, targetTDOABeta, targetTDOANoiseFloor], np.float32)
         self.dTarget.copy_(torch.from_numpy(self._target_host))
-        self._target_value, self._target_seen = float(self._target_host[0]), self._calls
+        self._target_value, self._target_dirty = float(self._target_host[0]), False
 
     @property
     def targetTDOAIndex(self):
-        """The tracked target TDOA index.  Only the online localisation (csrc/rt.hip) changes it on the device; without it the host copy
-        set by setTargetTDOARange IS the value.  With it, the value of the last device call is fetched at most once per call (from the
-        history mirror when that was downloaded anyway, else one 16-byte page-locked copy) -- repeated reads never touch the device."""
-        if not self.localizationEnabled:
-            return float(self._target_host[0])
-        if self._target_seen != self._calls:
+        """The tracked target TDOA index.  Only the online localisation (csrc/rt.hip) changes it on the device, and the masks always use the
+        device value -- so after tracking has run and ``localizationEnabled`` is switched off (the reference toggles it at run time,
+        gccNMFProcessor.py:112-116), the LAST TRACKED index stays the answer, not what setTargetTDOARange once set.  A device call that ran
+        with the localisation on marks the host copy stale; the value is then fetched at most once (from the history mirror when that
+        was downloaded anyway, else one 16-byte page-locked copy) -- repeated reads never touch the device."""
+        if self._target_dirty:
             if self._target_pin is None:
                 self._target_pin = torch.zeros(4, dtype=torch.float32).pin_memory()
             with torch.cuda.device(self.device):
                 self._target_pin.copy_(self.dTarget, non_blocking=True)
                 torch.cuda.current_stream(self.device).synchronize()
-            self._target_value, self._target_seen = float(self._target_pin[0]), self._calls
+            self._target_value, self._target_dirty = float(self._target_pin[0]), False
         return self._target_value
 
     @_on_device
     def _call(self, block_in, block_out, in_ring, out_ring, hop, block, frames_mode, out_delay_blocks=2):
         self._calls += 1
+        if self.localizationEnabled:
+            self._target_dirty = True
         _hip.check(self.lib.gccnmf_rt_process_block_ll(
             _ptr(block_in), _ptr(block_out), _ptr(in_ring), _ptr(out_ring), _ptr(self.dX), _ptr(self.dY), _ptr(self.dC), _ptr(self.dHMask),
             _ptr(self.dArgmax), _ptr(self.dTfMask), _ptr(self.dHist), _ptr(self.dHistPos), _ptr(self.dTarget), _ptr(self.dGccPhat),
@@ -194,7 +197,7 @@ class GCCNMFProcessor(object):
         self._mirror_host.copy_(self.dMirror, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         m, o, n = self._mirror_host.numpy(), self._mirror_offs, self._mirror_sizes
-        self._target_value, self._target_seen = float(m[o[4]]), self._calls              # the tracked index came along
+        self._target_value, self._target_dirty = float(m[o[4]]), False                  # the tracked index came along
         F, Tc, K, D = self.numFrequencies, self.numTimePerChunk, self.numAtom, self.numTDOAs
         cplx = lambda i: m[o[i]:o[i] + n[i]].reshape(2, F, Tc, 2).copy().view(np.complex64)[..., 0]
         X = cplx(0)

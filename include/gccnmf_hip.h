@@ -66,7 +66,7 @@ int gccnmf_version(void);
  * model in percent of a wide one (0 = built-in).
  * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
- * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..16, default 4).
+ * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..8, default 4).
  * key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4).  key 14: 1 (default) = H updates of at most 128
  * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.
  * keys 16 / 17: short dictionaries (K <= 128: the reference driver's K = 128, runGCCNMF.py:41), F = 64 n + 1 <= 513 -- two launches of an

@@ -1,6 +1,9 @@
 #!/bin/bash
 # The whole multi-GPU picture with one command, for whoever has an 8-GPU MI355X node (these build sessions lease ONE GPU):
 #     bash scripts/scale.sh [OUTDIR]        -> OUTDIR/scale.jsonl, one JSON line per (mode, N), each with n_gpus, ranks_seen, value, collective
+#                                           -> OUTDIR/SCALE_<mode>_N<n>.json, the complete bench.py line of that run (the shape of the driver's
+#                                              BENCH / SCALE records: metric, value, unit, n_gpus, steps, warmup, ms_per_step, scaling, config, ...)
+#                                           -> OUTDIR/SCALE_<mode>.json, {"mode", "runs": [that (mode, N) summary for N = 1, 2, 4, 8]}
 # Modes (with the scaling to expect):
 #   separate           independent files per rank, no data-path collective: near-linear (weak scaling; the driver's SCALE run)
 #   shared-dictionary  BASELINE config 4: one all-reduce of F*K+K floats (2.2 MB at K = 1024) per KL-NMF iteration over the library's own
@@ -19,6 +22,7 @@ for mode in separate shared-dictionary time-sharded; do
     [ "$n" -gt "$NGPU" ] && continue
     line=$(timeout 1200 python bench.py --gpus $n --mode $mode --steps 3 --warmup 1 --skip-extras 2> $OUT/${mode}_${n}.err | grep '^{' | tail -1)
     if [ -z "$line" ]; then echo "{\"mode\": \"$mode\", \"n_gpus\": $n, \"error\": \"see ${mode}_${n}.err\"}" | tee -a $OUT/scale.jsonl; continue; fi
+    echo "$line" > $OUT/SCALE_${mode}_N${n}.json
     echo "$line" | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
@@ -26,3 +30,10 @@ print(json.dumps({'mode': '$mode', 'n_gpus': d['n_gpus'], 'ranks_seen': d.get('r
                   'scaling': d['scaling'], 'collective': d.get('collective'), 'collective_backend': d.get('collective_backend')}))" | tee -a $OUT/scale.jsonl
   done
 done
+python - $OUT <<'PY'
+import json, os, sys
+out = sys.argv[1]
+rows = [json.loads(l) for l in open(os.path.join(out, 'scale.jsonl')) if l.strip()]
+for mode in sorted({r['mode'] for r in rows}):
+    json.dump({'mode': mode, 'runs': [r for r in rows if r['mode'] == mode]}, open(os.path.join(out, 'SCALE_%s.json' % mode), 'w'), indent=1)
+PY

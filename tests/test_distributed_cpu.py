@@ -216,6 +216,12 @@ def test_collective_timeout_and_ipc_environment_messages(monkeypatch):
     assert time.time() - t0 < 5
     msg = str(e.value)
     assert 'gccnmf_rccl_comm_init' in msg and 'GCCNMF_COLLECTIVE=torch' in msg and 'HSA_ENABLE_IPC_MODE_LEGACY' in msg
+    # inside the communicator set-up the same timeout is a RESULT, not an exception: the rank still takes part in the agreement all-reduce
+    # (its peers are waiting there) and every rank falls back to torch.distributed together (VERDICT r4 #8c)
+    t0 = time.time()
+    ok, why = D._try_rccl_init(lambda: time.sleep(30), 0.2, 'gccnmf_rccl_comm_init (rank 1 of 2, device cuda:1)')
+    assert ok is False and time.time() - t0 < 5 and 'did not return within' in why and 'GCCNMF_COLLECTIVE=torch' in why
+    assert D._try_rccl_init(lambda: True, 5, 'quick') == (True, None) and D._try_rccl_init(lambda: False, 5, 'refused') == (False, None)
     # a single process (no group) needs no exchange; an unknown route is an error only once a group exists
     hook = D.collective_hook(None)
     assert hook[0] is None and hook[3] == 'single rank'

@@ -47,6 +47,24 @@ def test_process_frames_matches_oracle(ws, K, D, Tc):
         assert out.shape == (2, ws, Tc) and out.dtype == np.float32
 
 
+@pytest.mark.parametrize('ws', [3838, 4094])
+def test_process_frames_at_the_largest_windows_off_the_powers_of_two(ws):
+    """Windows near the 4096 bound on the direct-sum kernels: their cos / sin table + frame image pass the 64 KB of dynamic LDS a launch
+    gets by default (the launcher raises the kernels' limit) -- the frames still match the oracle."""
+    dev, ora, rng = make(ws, 64, 32, 1, loc=False)
+    for p in (dev, ora):
+        p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    frames = (rng.standard_normal((2, ws, 1)) * 0.1).astype(np.float32)
+    out = dev.processFrames(frames)
+    ref, im = ora.processFrames(frames, return_intermediates=True)
+    d = dev.intermediates()
+    assert np.abs(d['X'] - im['X']).max() < 1e-4 * np.abs(im['X']).max()
+    assert np.mean(d['argmaxTDOA'] != im['argmaxTDOA']) < 2e-2
+    if (d['argmaxTDOA'] == im['argmaxTDOA']).all():
+        assert np.abs(out - ref).max() < 1e-3 * max(np.abs(ref).max(), 1e-6)
+    assert out.shape == (2, ws, 1) and np.isfinite(out).all()
+
+
 @pytest.mark.parametrize('ws,hop,B,K,D', [(1024, 512, 512, 64, 64), (512, 64, 64, 256, 64), (512, 128, 256, 128, 48)])
 def test_stream_matches_oracle_with_online_localisation(ws, hop, B, K, D):
     """Block-by-block streaming with TDOA tracking: the fused device call against OverlapAddOracle + processor oracle."""
@@ -73,6 +91,39 @@ def test_stream_matches_oracle_with_online_localisation(ws, hop, B, K, D):
     assert tdoa_dev == tdoa_ref                                            # the tracked target, block by block
     assert worst < 2e-4 * np.abs(x).max()
     assert np.isfinite(yd).all()
+
+
+def test_tracked_index_survives_switching_the_localisation_off():
+    """The reference toggles ``localizationEnabled`` at run time (gccNMFProcessor.py:112-116, the GUI checkbox) and keeps the last tracked
+    target.  So does the device (dTarget[0] stays what the tracking left and the masks keep using it) -- and so must the host property:
+    after tracking has moved the target away from what setTargetTDOARange set, switching the localisation off must not bring the
+    stale host copy back; the oracle processor is the witness, block by block, across the toggle."""
+    from gcc_nmf_amd.realtime import StreamingGCCNMF
+    ws, hop, B, K, D = 512, 64, 64, 128, 64
+    dev, ora, rng = make(ws, K, D, B // hop, seed=3, loc=True, L=6)
+    for p in (dev, ora):
+        p.setTargetTDOARange(9.6, 5.0, 2.0, 0.0)
+    x = O.synthetic_mixture(5, numSamples=16000, delays=(-3, 1, 4))
+    stream = StreamingGCCNMF(dev, hop, B)
+    ola = R.OverlapAddOracle(2, ws, hop, B, B // hop)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for b in range(60):
+            blk = x[:, b * B:(b + 1) * B]
+            stream.process_block(blk)
+            ola.processFrames(blk, ora.processFrames)
+        tracked = float(ora.targetTDOAIndex)
+        assert tracked != 9.6                                              # the tracking did move the target
+        dev.localizationEnabled = ora.localizationEnabled = False          # (no read of the property in between: the value is fetched after the toggle)
+        assert dev.targetTDOAIndex == tracked
+        for b in range(60, 80):
+            blk = x[:, b * B:(b + 1) * B]
+            yd = stream.process_block(blk)
+            yr = ola.processFrames(blk, ora.processFrames)
+            assert dev.targetTDOAIndex == float(ora.targetTDOAIndex) == tracked
+        assert np.abs(yd - yr).max() < 2e-4 * np.abs(x).max()              # the masks still steer at the tracked index
+        dev.setTargetTDOARange(20.0, 5.0, 2.0, 0.0)
+        assert dev.targetTDOAIndex == 20.0                                 # an explicit set wins again
 
 
 def test_process_stream_equals_block_calls_and_passthrough():
