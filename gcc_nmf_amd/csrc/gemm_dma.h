@@ -449,10 +449,12 @@ __host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int li
 // is empty -- work-conserving whatever the items cost; the ticket of the NEXT item is taken at the start of the current one, and the
 // next tile's first LDS-DMA pieces are issued BEFORE the current tile's epilogue (p.prefetch), so a workgroup's matrix pipe does not
 // wait for a prologue between two tiles.  The last workgroup to leave resets the counters (the next launch on the stream finds zeros).
-template <bool A_KC, bool B_KC, int EPI, bool TAIL, bool NARROW>
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
-    static_assert(!NARROW || EPI != EPI_UPDW, "the fused W update owns all rows and all 64 atoms of its tile");
-    constexpr int TM = 4, BK = 16, BM = 128 * TM, BN = 64, RW = 32 * TM;      // RW: rows per wave
+    static_assert(TM == 4 || TM == 2, "");
+    static_assert(TM == 4 || EPI != EPI_UPDW, "the fused W update owns all rows of its atoms: full-height tiles only");
+    static_assert(!NARROW || (EPI != EPI_UPDW && TM == 4), "narrow items: full-height tiles with an element-wise epilogue");
+    constexpr int BK = 16, BM = 128 * TM, BN = 64, RW = 32 * TM;      // RW: rows per wave
     constexpr int NA = 2 * TM;                                         // 1 KB LDS-DMA pieces of the A tile per wave
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
@@ -819,6 +821,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             trace_row[4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
             trace_row[7] = (long long)blockIdx.x << 16 | (long long)it;
         }
+#ifdef GCCNMF_EXPERIMENTS
         set_lane_constants(gemm_opaque_tid());
         if (it > 0) set_offsets(lane);
         // every fragment register starts an item defined: a conditional read followed by an unconditional tie would otherwise keep the
@@ -826,6 +829,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         a0.clear(); a1.clear(); b0.clear(); b1.clear();
         sc0 = sc1 = t4 = tb4 = ts4 = rs4 = zero4;
         tbxy = tbzw = gemm_f32x2{0.f, 0.f};
+#else
+        set_lane_constants(tid);
+#endif
         // ---- prologue: tile 0 -> buffer 0 (unless the previous item's epilogue already sent it), group 0 of tile 0 into registers
         if (!prefetched) {
 #pragma unroll
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         if constexpr (EPI == EPI_UPDW) {
             // launch_rht_update_w guarantees M % 128 == 0 and N % 64 == 0 (a second, generic variant in this kernel would
             // double the live ranges of the accumulators and spill the main loop)
-            gemm_epilogue_update_w_full<TAIL>(p, e_file, e_col0, tid, wm, l31, hh, e_active, acc, tail_acc, rowsum_acc, scratch);
+            if constexpr (TM == 4) gemm_epilogue_update_w_full<TAIL>(p, e_file, e_col0, tid, wm, l31, hh, e_active, acc, tail_acc, rowsum_acc, scratch);
         } else {
             if (e_active) {
                 const int row_w = e_row0 + wm * RW;                           // wave-uniform
@@ -911,11 +917,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
                         }
                         e0.finish(p, e_file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
                         if (trace_row && tid == 0) trace_row[5] = __builtin_amdgcn_s_memrealtime();
-                        e0.load(p, e_file, row_w + 64, hh, ca, cb);
+                        if constexpr (TM == 4) e0.load(p, e_file, row_w + 64, hh, ca, cb);
                         e1.finish(p, e_file, row_w + 32, tr + 32, hh, ca, ba, bb, s_rowvec, acc[1][0], acc[1][1], oka, okb, cb);
-                        e1.load(p, e_file, row_w + 96, hh, ca, cb);
-                        e0.finish(p, e_file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
-                        e1.finish(p, e_file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
+                        if constexpr (TM == 4) {
+                            e1.load(p, e_file, row_w + 96, hh, ca, cb);
+                            e0.finish(p, e_file, row_w + 64, tr + 64, hh, ca, ba, bb, s_rowvec, acc[2][0], acc[2][1], oka, okb, cb);
+                            e1.finish(p, e_file, row_w + 96, tr + 96, hh, ca, ba, bb, s_rowvec, acc[3][0], acc[3][1], oka, okb, cb);
+                        }
                         if (trace_row && tid == 0) trace_row[6] = __builtin_amdgcn_s_memrealtime();
                     }
                 }
@@ -972,130 +980,62 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 }
 
 // ---- host side: the plan of a launch -----------------------------------------------------------------------------------------
-// How many wide tiles at the end of every list run as two narrow halves (GemmArgs.split): chosen by a list-scheduling model of ONE
-// list on its XCD -- 32 CUs x 2 workgroup slots taking items in order; an item advances at 1 / 250 of a wide tile per microsecond
-// beside a neighbour on its CU and at 1 / 135 alone (profiles/r02k_files_sweep.txt: a paired round of full tiles 0.25 ms, a workgroup
-// alone on its CU 0.135 ms at Kd = 1024; everything scales alike with Kd), a narrow item is GEMM_DMA_NARROW_COST of a wide one.
-// Results are cached per (wide, ragged) list length.
-#ifndef GEMM_DMA_NARROW_COST
-#define GEMM_DMA_NARROW_COST 0.59      // measured: K1 over 64 files with every tile split (profiles/r05a_kbench_all_narrow.txt) 0.786 ms against 0.663
-#endif
 extern int gccnmf_tune_tail_split;      // key 9
+#ifdef GCCNMF_EXPERIMENTS
 extern int gccnmf_tune_persistent;      // key 18
 extern int gccnmf_tune_prefetch;        // key 19
-extern int gccnmf_tune_narrow_cost;     // key 20: cost of a narrow item in percent of a wide one (0 = GEMM_DMA_NARROW_COST)
 unsigned* gccnmf_ticket_block(hipStream_t stream);
+#endif
 
-static double gemm_dma_makespan(int wide, int halves, int ragged, double narrow) {
-    constexpr int CUS = 32;
-    const double rp = 1.0 / 250.0, ra = 1.0 / 135.0;
-    double left[CUS][2];
-    bool busy[CUS][2];
-    for (int c = 0; c < CUS; ++c) busy[c][0] = busy[c][1] = false;
-    int next = 0;
-    const int total = wide + halves + ragged;
-    auto cost = [&](int i) { return i < wide ? 1.0 : narrow; };
-    auto fill = [&]() {
-        for (int s = 0; s < 2 && next < total; ++s)
-            for (int c = 0; c < CUS && next < total; ++c)
-                if (!busy[c][s]) {
-                    busy[c][s] = true;
-                    left[c][s] = cost(next++);
-                }
-    };
-    double t = 0.0;
-    fill();
-    for (;;) {
-        double dt = -1.0;
-        for (int c = 0; c < CUS; ++c) {
-            const int nb = (busy[c][0] ? 1 : 0) + (busy[c][1] ? 1 : 0);
-            if (!nb) continue;
-            const double r = nb == 2 ? rp : ra;
-            for (int s = 0; s < 2; ++s)
-                if (busy[c][s] && (dt < 0.0 || left[c][s] / r < dt)) dt = left[c][s] / r;
-        }
-        if (dt < 0.0) return t;
-        for (int c = 0; c < CUS; ++c) {
-            const int nb = (busy[c][0] ? 1 : 0) + (busy[c][1] ? 1 : 0);
-            if (!nb) continue;
-            const double r = nb == 2 ? rp : ra;
-            for (int s = 0; s < 2; ++s)
-                if (busy[c][s]) {
-                    left[c][s] -= dt * r;
-                    if (left[c][s] < 1e-9) busy[c][s] = false;
-                }
-        }
-        t += dt;
-        fill();
-    }
-}
-
-static int gemm_dma_plan_split(int cw, int cr) {
-    if (cw < 1) return 0;
-    static std::mutex mu;
-    static int cache_key[64][3], cache_val[64], cached = 0;
-    const int pct = gccnmf_tune_narrow_cost;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < cached; ++i)
-        if (cache_key[i][0] == cw && cache_key[i][1] == cr && cache_key[i][2] == pct) return cache_val[i];
-    const double narrow = pct > 0 ? pct / 100.0 : GEMM_DMA_NARROW_COST;
-    int best = 0;
-    double best_t = gemm_dma_makespan(cw, 0, cr, narrow);
-    const int smax = cw < 64 ? cw : 64;
-    for (int s = 2; s <= smax; s += 2) {
-        const double ts = gemm_dma_makespan(cw - s, 2 * s, cr, narrow);
-        if (ts < best_t * 0.985) {          // a split has to buy at least 1.5 %
-            best_t = ts;
-            best = s;
-        }
-    }
-    const int slot = cached < 64 ? cached++ : 63;
-    cache_key[slot][0] = cw; cache_key[slot][1] = cr; cache_key[slot][2] = pct;
-    cache_val[slot] = best;
-    return best;
-}
-
-// The plan of one launch over the files [a.file0, a.file0 + a.batch): tile counts, the per-XCD lists, how many tiles are split.
-// narrow_capable: the kernel instantiation carries the 512 x 32 loop.  Returns the size of the classic grid (items of the longest list x lists).
-static int gemm_dma_plan(GemmArgs& a, bool narrow_capable) {
-    a.tiles_m = gccnmf_ceil_div(a.M, 512);
+// The work lists of one launch of TM-high tiles over the files [a.file0, a.file0 + a.batch).  narrow_capable: the kernel instantiation
+// carries the 512 x 32 loop.  Returns the size of the classic grid (items of the longest list x lists), -1 on overflow.
+//   key 9 = 0: wide tiles only | 1 (default): a file's ragged last column tile (at most 32 of its 64 columns exist) becomes a narrow item
+//   when the launch shares the chip with another file group's launches (its early finish is used at once), or when the extra items do not
+//   cost the launch another round of workgroup slots (51 files: 128 tiles per XCD fit two rounds of 64, 122 + 7 items do not) | 2 (tests):
+//   every tile as two narrow halves
+static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM) {
+    a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
-    const int policy = gccnmf_tune_tail_split;                          // 0: wide tiles only | 1: by the model | 2: every tile as two narrow halves
-    const bool narrow_ok = narrow_capable && policy != 0;
-    a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;
-    a.wide_n = a.tiles_n - a.rag;
     a.lists = (a.xcd_affine && a.batch >= 8) ? 8 : 1;
+    const int policy = gccnmf_tune_tail_split;
+    const bool narrow_ok = narrow_capable && TM == 4 && policy != 0;
+    const long tiles = (long)a.batch * a.tiles_m * a.tiles_n;
+    if (tiles > (1L << 28)) return -1;
+    a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;
+    if (a.rag && policy == 1 && !a.concurrent) {
+        const long slots = a.lists == 8 ? 64 : 512;
+        const long plain = (tiles + a.lists - 1) / a.lists;
+        const long with_rag = ((long)a.batch * a.tiles_m * (a.tiles_n - 1) + a.lists - 1) / a.lists + ((long)a.batch * a.tiles_m + a.lists - 1) / a.lists;
+        if ((with_rag + slots - 1) / slots > (plain + slots - 1) / slots) a.rag = 0;
+    }
+    a.wide_n = a.tiles_n - a.rag;
     const long wide = (long)a.batch * a.tiles_m * a.wide_n, ragged = (long)a.batch * a.rag * a.tiles_m;
-    if (wide + ragged > (1L << 28)) return -1;
     a.cw = (int)((wide + a.lists - 1) / a.lists);
     a.cr = (int)((ragged + a.lists - 1) / a.lists);
-    a.split = 0;
-    if (narrow_ok) {
-        if (policy == 2) a.split = a.cw;
-        else if (!a.concurrent && a.lists == 8 && !gccnmf_trace_buf) a.split = gemm_dma_plan_split(a.cw, a.cr);
-    }
+    a.split = (narrow_ok && policy == 2) ? a.cw : 0;
     return a.lists * (a.cw + a.split + a.cr);
 }
 
-// One launch of the LDS-DMA tile over the files [a.file0, a.file0 + a.batch).
-template <bool A_KC, bool B_KC, int EPI, bool TAIL>
-static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
-    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
-    if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
-    constexpr bool NARROW = (EPI == EPI_DIV || EPI == EPI_UPDH || EPI == EPI_STORE);
-    a.ablate = gccnmf_tune_ablate;
-    a.exact_div = gccnmf_tune_exact_div;
-    const int classic_grid = gemm_dma_plan(a, NARROW);
+// One launch of TM-high tiles over the files [a.file0, a.file0 + a.batch)
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM>
+static int gccnmf_launch_gemm_dma_tm(GemmArgs a, hipStream_t stream) {
+#ifdef GEMM_DMA_NO_NARROW           // A/B build: no instantiation carries the narrow loop
+    constexpr bool NARROW = false;
+#else
+    constexpr bool NARROW = TM == 4 && (EPI == EPI_DIV || EPI == EPI_UPDH || EPI == EPI_STORE);
+#endif
+    const int classic_grid = gemm_dma_plan(a, NARROW, TM);
     if (classic_grid < 1) return GCCNMF_ERR_ARG;
     a.trace = gccnmf_trace_buf;
     a.trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks : 0;
     a.trace_grid = classic_grid;
     a.tickets = nullptr;
-    a.prefetch = gccnmf_tune_prefetch;
+    a.prefetch = 0;
     a.wpl = 0;
     int grid = classic_grid;
 #ifdef GCCNMF_EXPERIMENTS
-    if (gccnmf_tune_persistent && classic_grid > 512) {
+    a.prefetch = gccnmf_tune_prefetch;
+    if (gccnmf_tune_persistent && TM == 4 && classic_grid > 512) {
         a.tickets = gccnmf_ticket_block(stream);
         if (a.tickets) {
             grid = 512;
@@ -1103,7 +1043,58 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
         }
     }
 #endif
-    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, NARROW>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gccnmf_gemm_dma_kernel<A_KC, B_KC, EPI, TAIL, TM, NARROW>), dim3(grid), dim3(256), 0, stream, a);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
+}
+
+// A launch is whole rounds of 512 workgroups (two per CU) plus a partial one, and a partial round costs 0.135 ms however few
+// workgroups it holds (a workgroup alone on its CU: profiles/r02k_files_sweep.txt).  When that pays, the files the partial round
+// would take run as a second launch of HALF-HEIGHT tiles (TM = 2: 256 x 64 per workgroup, 64 x 64 per wave, three workgroups per CU)
+// instead: twice the workgroups at half the length (80 files: 3 rounds + 64 tiles -> 76 files + 4 files as 160 half tiles, one per CU for
+// a third of the time); a launch of less than one round may run entirely on half-height tiles (16 files: 640 of them, three per CU).
+// Whole files only, same k order per output element, so a file's bits do not depend on which launch it rides in.  Outputs of at most 256
+// rows (the H update of a dictionary of up to 256 atoms) ALWAYS take half-height tiles: a full tile would leave two of its four waves idle.
+// Round 5 measured two alternatives on one box against this policy and kept it (profiles/r05b_files_sweep*.txt): narrow halves of the
+// last tiles chosen by a list-scheduling model, and 512 resident workgroups pulling tiles by ticket -- LABBOOK.md.
+template <bool A_KC, bool B_KC, int EPI, bool TAIL>
+static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
+    if (!a.A || !a.B || !a.C || a.M < 1 || a.N < 1 || a.Kd < 1 || a.batch < 1) return GCCNMF_ERR_ARG;
+    if ((a.lda & 3) || (a.ldb & 3)) return GCCNMF_ERR_ARG;
+    a.ablate = gccnmf_tune_ablate;
+    a.exact_div = gccnmf_tune_exact_div;
+    if constexpr (EPI != EPI_UPDW) {
+        if (a.M <= 256 && gccnmf_tune_tail_split != 0) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+        const long tpf = (long)gccnmf_ceil_div(a.M, 512) * gccnmf_ceil_div(a.N, 64);     // throughput tiles per file
+        const long total = tpf * a.batch, rounds = total / 512;
+        // Decided by a cost model in units of one paired round of full tiles = 250 (measured at Kd = 1024: 0.25 ms; everything scales
+        // with Kd alike): a partial round of <= 256 full tiles costs 135 (one workgroup alone per CU), a larger one a whole round;
+        // half-height workgroups (130-170 VGPRs, 43 KB of LDS: three per CU, 768 per round) cost 85 up to one per CU, 135 up to two,
+        // 190 for three; a second launch costs 10 (profiles/r03g_files_sweep.txt, r03k_files_sweep.txt).
+        if (gccnmf_tune_tail_split == 1 && !gccnmf_trace_buf && !a.concurrent && a.M > 256) {
+            // three forms, priced for a launch that has the chip to itself: all full tiles | whole rounds of full tiles + the rest
+            // of the files half-height | everything half-height (768 per round: 32 files 0.389 -> 0.330 ms, 16 files 0.249 -> 0.192)
+            auto full_cost = [](long tiles) { const long r = tiles % 512; return (tiles / 512) * 250 + (r == 0 ? 0 : r <= 256 ? 135 : 250); };
+            auto half_cost = [](long halves) {
+                const long r = halves % 768;
+                return (halves / 768) * 190 + (r == 0 ? 0 : r <= 256 ? 85 : r <= 512 ? 135 : 190);
+            };
+            const long plain = full_cost(total), all_half = half_cost(2 * total);
+            long split = 1L << 40;
+            const int head = (int)(rounds * 512 / tpf);              // whole files that fit the whole rounds
+            const int rest = a.batch - head;
+            if (rounds >= 1 && head >= 8 && rest >= 1 && 2 * rest * tpf <= 768) split = full_cost(head * tpf) + half_cost(2 * rest * tpf) + 10;
+            if (all_half < plain && all_half <= split) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+            if (split < plain) {
+                GemmArgs h = a, t = a;
+                h.batch = head;
+                t.batch = rest;
+                t.file0 = a.file0 + head;
+                int rc = gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(h, stream);
+                if (rc) return rc;
+                return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(t, stream);
+            }
+        }
+    }
+    return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 4>(a, stream);
 }

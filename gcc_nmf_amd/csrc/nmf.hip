@@ -21,12 +21,15 @@ int gccnmf_tune_ablate = 0;
 #define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
                                      // the ring / throughput kernels win anyway: 8 files 41.5 against 41.3 ms, 12 files 61.9 against 59.3)
 int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
-int gccnmf_tune_tail_split = 1;       // key 9: 1 (default) = a throughput-tile launch may hold narrow (512 x 32) items: a file's ragged last column tile, and the
-                                      // end of each XCD's list split by the list-scheduling model (gemm_dma.h); 0 = wide tiles only; 2 = every tile as two halves
-int gccnmf_tune_persistent = 0;       // key 18 (experiment builds only): 1 = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
-int gccnmf_tune_prefetch = 1;         // key 19 (experiment builds only): 1 = a resident workgroup requests its next item's first k-tile before the current item's epilogue
-int gccnmf_tune_narrow_cost = 0;      // key 20: cost of a narrow item in the split model, percent of a wide one (0 = built-in)
-int gccnmf_tune_exact_div = 0;     // 1: V / (W.H) of the throughput tile is the IEEE quotient (default: rcp + one Newton step, <= 1 ulp off in rare cases)
+int gccnmf_tune_tail_split = 1;       // key 9: 1 (default) = the launcher of the throughput tile picks the form (gemm_dma.h): half-height tiles for the files of a
+                                      // partial last round / for outputs of at most 256 rows, a narrow (512 x 32) item for a file's ragged last column tile;
+                                      // 0 = full 512 x 64 tiles only; 2 = every full tile as two narrow halves (tests)
+#ifdef GCCNMF_EXPERIMENTS
+int gccnmf_tune_persistent = 0;       // key 18: 1 = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
+int gccnmf_tune_prefetch = 1;         // key 19: 1 = a resident workgroup requests its next item's first k-tile before the current item's epilogue
+#endif
+int gccnmf_tune_exact_div = 1;     // key 7: 1 (default since round 5) = V / (W.H) of the throughput tile is the IEEE quotient, like numpy.divide in the reference;
+                                   // 0 = v_rcp_f32 + one Newton step (<= 1 ulp off in rare cases).  Measured cost of the exact form: 0.0 % on K1 / K3 (profiles/r05b_*)
 int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
 int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
 int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
@@ -71,6 +74,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_tail_split = value;
         return GCCNMF_OK;
     }
+#ifdef GCCNMF_EXPERIMENTS
     if (key == 18 && (value == 0 || value == 1)) {
         gccnmf_tune_persistent = value;
         return GCCNMF_OK;
@@ -79,10 +83,7 @@ int gccnmf_set_tuning(int key, int value) {
         gccnmf_tune_prefetch = value;
         return GCCNMF_OK;
     }
-    if (key == 20 && value >= 0 && value <= 100) {
-        gccnmf_tune_narrow_cost = value;
-        return GCCNMF_OK;
-    }
+#endif
     if (key == 8 && value >= 1 && value <= GCCNMF_SHARED_STREAMS) {
         gccnmf_tune_shared_groups = value;
         return GCCNMF_OK;
@@ -132,6 +133,7 @@ int gccnmf_set_tuning(int key, int value) {
 
 }  // extern "C"
 
+#ifdef GCCNMF_EXPERIMENTS
 // Ticket blocks of the persistent throughput-tile launches (gemm_dma.h): 16 counters per (device, stream), zero between launches (the last
 // workgroup of a launch resets them).  Launches on one stream are serialised, so a stream's launches share a block; every stream has its own.
 // nullptr (pool exhausted, allocation refused -- e.g. inside a stream capture) = the launch falls back to the classic grid.
@@ -165,6 +167,8 @@ unsigned* gccnmf_ticket_block(hipStream_t stream) {
     entries[dev][used[dev]].s = stream;
     return pool[dev] + 16 * used[dev]++;
 }
+
+#endif
 
 extern "C" {
 int gccnmf_debug_set_trace(long long* buf, int blocks) {
@@ -1306,7 +1310,7 @@ int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurre
     if (M < 1 || N < 1 || batch < 1 || !plan || (max_items > 0 && !items)) return -1;
     GemmArgs a = {};
     a.M = M; a.N = N; a.batch = batch; a.xcd_affine = xcd_affine; a.concurrent = concurrent;
-    const int grid = gemm_dma_plan(a, narrow_capable != 0);
+    const int grid = gemm_dma_plan(a, narrow_capable != 0, 4);
     if (grid < 1) return -1;
     const int fields[8] = {a.lists, a.cw, a.cr, a.split, a.rag, a.tiles_m, a.tiles_n, grid};
     for (int i = 0; i < 8; ++i) plan[i] = fields[i];

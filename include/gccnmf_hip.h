@@ -53,17 +53,15 @@ int gccnmf_version(void);
  * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
  * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs).
  * key 4: 1 (default) = small launches run on the LDS-DMA ring kernel (csrc/gemm_ring.h).  keys 5 / 6: parts of the single-file
- * split-K reductions (W.H / R.H^T).  key 7: 1 = the throughput tile's V / (W.H) epilogue divides IEEE-exactly like numpy.divide
- * (default 0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the
- * small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
+ * split-K reductions (W.H / R.H^T).  key 7: 1 (default) = the throughput tile's V / (W.H) epilogue divides IEEE-exactly like numpy.divide
+ * (0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the exact form was
+ * measured to cost nothing in the MFMA-bound launch, round 5; the small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
  * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
- * key 9: 1 (default) = a throughput-tile launch may hold NARROW (512 x 32) items next to its 512 x 64 tiles: a file's ragged last
- * column tile when at most 32 of its columns exist, and the last tiles of each XCD's list split in two by a list-scheduling model of
- * the launch (it has to have the chip to itself) -- same k order per element, bitwise the same results in every form; 0 = wide tiles
- * only; 2 = every tile as two narrow halves (tests).  key 18: 1 (default) = launches of more than 512 items run as 512 RESIDENT
- * workgroups that pull items through a ticket counter (work-conserving; the classic grid otherwise).  key 19: 1 (default) = a resident
- * workgroup requests its next item's first k-tile before the current item's epilogue.  key 20: cost of a narrow item in the split
- * model in percent of a wide one (0 = built-in).
+ * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
+ * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout; outputs
+ * of at most 256 rows always take half-height tiles; a file's ragged last column tile (at most 32 of its 64 columns exist: N = 1244)
+ * becomes a NARROW (512 x 32) item at the end of its XCD's list when that does not cost the launch another round of workgroup slots.
+ * Same k order per element: bitwise the same results in every form.  0 = full tiles only; 2 = every full tile as two narrow halves (tests).
  * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..8, default 4).

@@ -49,7 +49,7 @@ for exact in (0, 1):
     W, H = e.get_WH()
     am[('W', exact)] = W
     del e
-lib.gccnmf_set_tuning(7, 0)
+lib.gccnmf_set_tuning(7, 1)          # back to the default (IEEE division since round 5)
 d = am[0] != am[1]
 out['bench_files'] = {'coefficients': int(d.size), 'flips_between_division_modes': int(d.sum()), 'files_with_flips': int(d.any(axis=(1, 2)).sum()),
                       'W_rel_between_modes': rel(am[('W', 0)], am[('W', 1)])}

@@ -573,11 +573,12 @@ def test_klnmf_batch_is_file_independent(hip):
     assert rel(Wp[8, :F, :K], Wr) < 1e-4 and rel(Hp[8, :K, :N], Hr) < 1e-4
 
 
-@pytest.mark.parametrize('F,T,K,B,flags', [(513, 622, 64, 26, 0), (513, 330, 512, 50, 0), (513, 200, 1024, 70, 2), (513, 622, 96, 64, 0)])
+@pytest.mark.parametrize('F,T,K,B,flags', [(513, 622, 64, 26, 0), (513, 330, 512, 50, 0), (513, 200, 1024, 70, 2), (513, 622, 96, 64, 0), (513, 330, 256, 40, 0)])
 def test_narrow_items_and_resident_workgroups_are_bitwise(hip, F, T, K, B, flags):
-    """The throughput-tile launch in every form it can take (csrc/gemm_dma.h): wide tiles only on the classic grid (key 9 = 0, key 18 = 0:
-    the reference form) | narrow ragged tiles + model-chosen splits (key 9 = 1) | every tile as two narrow halves (key 9 = 2) | 512 resident
-    workgroups pulling items by ticket (key 18), with and without the next item's first k-tile requested under the epilogue (key 19).
+    """The throughput-tile launch in every form it can take (csrc/gemm_dma.h): full 512 x 64 tiles only (key 9 = 0: the reference form) |
+    the launcher's own choice -- half-height tiles for the files of a partial last round and for outputs of at most 256 rows, a narrow
+    item for a file's ragged last column tile (key 9 = 1) | every tile as two narrow halves (key 9 = 2) | in an experiment build, 512
+    resident workgroups pulling items by ticket (key 18), with and without the next item's first k-tile requested under the epilogue (19).
     Every output element sees the same k order in each of them: W and H are bit for bit those of the reference form.
     (K1/K3 at 26 x 20 = 520 items; the H update at K = 512, 50 x 11 = 550; the unfused R.H^T at K = 1024, 70 x 16 = 1120; 64 files.)"""
     lib = hip.lib()
@@ -589,30 +590,31 @@ def test_narrow_items_and_resident_workgroups_are_bitwise(hip, F, T, K, B, flags
     W0, H0 = klnmf_initial_factors(F, N, K)
     dV = padded(V, (B, g.Fp, g.Np), 'cuda')
     outs = []
-    forms = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (0, 1, 0), (1, 1, 1), (2, 1, 1), (1, 1, 0)]
+    forms = [(0, 0, 0), (1, 0, 0), (2, 0, 0)]
+    if lib.gccnmf_set_tuning(18, 0) == 0:              # an experiment build (make EXPERIMENTS=1) also carries the resident-workgroup grid
+        forms += [(0, 1, 0), (1, 1, 1), (2, 1, 1), (1, 1, 0)]
     try:
         for narrow, resident, prefetch in forms:
-            assert lib.gccnmf_set_tuning(9, narrow) == 0 and lib.gccnmf_set_tuning(18, resident) == 0 and lib.gccnmf_set_tuning(19, prefetch) == 0
+            assert lib.gccnmf_set_tuning(9, narrow) == 0
+            if len(forms) > 3:
+                assert lib.gccnmf_set_tuning(18, resident) == 0 and lib.gccnmf_set_tuning(19, prefetch) == 0
             assert lib.gccnmf_set_tuning(16, 0) == 0 and lib.gccnmf_set_tuning(17, 0) == 0          # K <= 128: the four-launch form, on the throughput tile
             dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
             dH = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
             ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
-            for rep in range(2):          # twice: the second call finds the ticket counters as the first one left them
-                assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, 3 - rep, 0.1, 1e-16, flags, stream()) == 0
-                if rep == 0:
-                    first = (dW.cpu().numpy(), dH.cpu().numpy())
-                    dW.copy_(padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda'))
-                    dH.copy_(padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda'))
-            outs.append(first)
+            assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, 3, 0.1, 1e-16, flags, stream()) == 0
+            outs.append((dW.cpu().numpy(), dH.cpu().numpy()))
+            # once more on the same stream: a resident-workgroup launch finds the ticket counters as the previous one left them
+            assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, 1, 0.1, 1e-16, flags, stream()) == 0
     finally:
-        for key, value in ((9, 1), (18, 1), (19, 1), (16, 1), (17, 1)):
+        for key, value in ((9, 1), (18, 0), (19, 1), (16, 1), (17, 1)):
             lib.gccnmf_set_tuning(key, value)
     for form, (Wq, Hq) in zip(forms[1:], outs[1:]):
         assert np.array_equal(outs[0][0], Wq) and np.array_equal(outs[0][1], Hq), form
-    Wp, Hp = outs[4]
+    Wp, Hp = outs[1]
     assert not Wp[:, F:, :].any() and not Wp[:, :, K:].any() and not Hp[:, K:, :].any() and not Hp[:, :, N:].any()      # padding stayed zero
     Wr, Hr = O.performKLNMF(V[B - 1], K, 3, 0.1)                      # a file of the last round against the oracle
-    assert rel(outs[4][0][B - 1, :F, :K], Wr) < 1e-4 and rel(outs[4][1][B - 1, :K, :N], Hr) < 1e-4
+    assert rel(outs[1][0][B - 1, :F, :K], Wr) < 1e-4 and rel(outs[1][1][B - 1, :K, :N], Hr) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------

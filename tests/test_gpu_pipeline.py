@@ -368,23 +368,22 @@ def test_nmf_file_groups_on_streams_are_bitwise_the_single_stream_result():
 
 @pytest.mark.parametrize('K', [512, 1024])
 def test_narrow_items_in_the_one_shot_gemms_are_bitwise(K):
-    """Tuning keys 9 / 18 in the whole pipeline at a batch whose one-shot GEMMs end in a small partial round (9 files: the score GEMM's
-    270 / 540 tiles may be split by the model; the reconstruction GEMM keeps wide tiles): scores, masks, spectrogram estimates and
-    waveforms bit for bit those of the wide-tiles-only classic grid."""
+    """Tuning key 9 in the whole pipeline at a batch whose one-shot GEMMs end in a small partial round (9 files: reconstruction
+    9 x 60 = 540 tiles -> 8 files + 1 file as half-height tiles; the score GEMM at K = 512: 270 tiles, all half-height; key 9 = 2: the
+    score GEMM's tiles as narrow halves): scores, masks, spectrogram estimates and waveforms bit for bit those of the full-tiles-only form."""
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.synthetic import synthetic_batch
     lib = _hip.lib()
     xs = synthetic_batch(40, 9)
     outs = []
     try:
-        for narrow, resident in ((0, 0), (1, 1), (2, 1)):
-            assert lib.gccnmf_set_tuning(9, narrow) == 0 and lib.gccnmf_set_tuning(18, resident) == 0
+        for narrow in (0, 1, 2):
+            assert lib.gccnmf_set_tuning(9, narrow) == 0
             e = engine(160000, dictionarySize=K, numIterations=3, batch=9)
             y = e.separate(xs)
             outs.append((y, e.get_scores(), e.get_argmax(), e.get_spec(), e.get_WH()))
     finally:
         lib.gccnmf_set_tuning(9, 1)
-        lib.gccnmf_set_tuning(18, 1)
     for other in outs[1:]:
         for a, b in zip(outs[0][:4], other[:4]):
             assert np.array_equal(a, b)

@@ -76,7 +76,7 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_run(None, 9, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # > GCCNMF_MAX_SHARDS
     assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
     assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 3) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
-    assert lib.gccnmf_set_tuning(18, 2) == 1 and lib.gccnmf_set_tuning(19, 2) == 1 and lib.gccnmf_set_tuning(20, 101) == 1
+    assert lib.gccnmf_set_tuning(18, 2) == 1 and lib.gccnmf_set_tuning(19, 2) == 1
     assert lib.gccnmf_set_tuning(10, 2) == 1 and lib.gccnmf_set_tuning(11, 9) == 1 and lib.gccnmf_set_tuning(12, 17) == 1
     assert lib.gccnmf_set_tuning(16, 3) == 1 and lib.gccnmf_set_tuning(17, 3) == 1 and lib.gccnmf_set_tuning(17, 1) == 0 and lib.gccnmf_set_tuning(16, 1) == 0
     d = _hip.DirectGemm()
@@ -95,16 +95,16 @@ def _gemm_plan(lib, M, N, batch, xcd=1, concurrent=0, narrow=1):
 
 def test_throughput_tile_work_lists_cover_every_tile_exactly_once():
     """The ordered item lists of a throughput-tile launch (csrc/gemm_dma.h; gccnmf_debug_gemm_plan runs the kernel's own tile decode on
-    the host): in every form -- wide tiles only, narrow ragged tiles + model-chosen splits, everything split -- each 32-column block of
-    every (file, row tile) is computed by exactly one item, items of a list are ordered longest first, and a ragged last column tile
-    (N = 1244 = 19 x 64 + 28) costs one narrow item instead of a padded wide one."""
+    the host): in every form -- wide tiles only, narrow ragged tiles, everything split -- each 32-column block of every (file, row tile)
+    is computed by exactly one item, items of a list are ordered longest first, and a ragged last column tile (N = 1244 = 19 x 64 + 28)
+    costs one narrow item instead of a padded wide one where that does not cost the launch another round of workgroup slots."""
     from gcc_nmf_amd import _hip
     lib = _hip.lib()
     try:
         for policy in (0, 1, 2):
             assert lib.gccnmf_set_tuning(9, policy) == 0
             for M, N, B in [(512, 1244, 64), (512, 1244, 26), (1024, 1244, 64), (512, 1244, 5), (300, 100, 9), (512, 1280, 32), (512, 1244, 72),
-                            (512, 1244, 16), (512, 1244, 40), (512, 33, 8), (512, 32, 8), (1536, 1244, 13), (512, 660, 50)]:
+                            (512, 1244, 16), (512, 1244, 40), (512, 33, 8), (512, 32, 8), (1536, 1244, 13), (512, 660, 50), (512, 1244, 51)]:
                 for concurrent in (0, 1):
                     pl, items = _gemm_plan(lib, M, N, B, 1, concurrent)
                     cover = np.zeros((B, pl['tiles_m'], 2 * pl['tiles_n']), int)
@@ -123,12 +123,15 @@ def test_throughput_tile_work_lists_cover_every_tile_exactly_once():
                         assert pl['rag'] == 0 and pl['split'] == 0 and np.all(items[:, 5] == 2)
                     if policy == 2:
                         assert np.all(items[:, 5] == 1)
-                    if concurrent and policy == 1:
-                        assert pl['split'] == 0                  # a launch that shares the chip keeps whole tiles (the other group fills the gaps)
-        # the headline shape: 19 wide + 1 narrow item per file instead of 20 wide ones; nothing to split at 64 files
+                    if policy == 1:
+                        assert pl['split'] == 0
         assert lib.gccnmf_set_tuning(9, 1) == 0
+        # the headline shape: 19 wide + 1 narrow item per file instead of 20 wide ones (152 + 8 = the 160 slots per XCD the padded tiles take)
         pl, items = _gemm_plan(lib, 512, 1244, 64)
         assert (pl['cw'], pl['cr'], pl['split'], pl['rag']) == (152, 8, 0, 1) and (items[:, 5] == 1).sum() == 64
+        # 51 files: 128 padded tiles per XCD are exactly two rounds of 64 slots, 122 + 7 items would start a third -> wide tiles, unless the
+        # launch shares the chip with another file group's (its early finishers are used at once)
+        assert _gemm_plan(lib, 512, 1244, 51)[0]['rag'] == 0 and _gemm_plan(lib, 512, 1244, 51, concurrent=1)[0]['rag'] == 1
         # a kernel instantiation without the narrow loop never gets narrow items
         pl, items = _gemm_plan(lib, 512, 1244, 26, narrow=0)
         assert pl['rag'] == 0 and pl['split'] == 0 and np.all(items[:, 5] == 2) and len(items) == 520
