@@ -59,9 +59,11 @@ static_assert(sizeof(ncclUniqueId) == GCCNMF_RCCL_UNIQUE_ID_BYTES, "unique id si
 
 extern "C" {
 
-int gccnmf_rccl_available(void) { return rccl().ok ? 1 : 0; }
+int gccnmf_rccl_available(void) {
+    GCCNMF_ENTER(); return rccl().ok ? 1 : 0; }
 
 int gccnmf_rccl_unique_id(char* id_bytes) {
+    GCCNMF_ENTER();
     if (!id_bytes) return GCCNMF_ERR_ARG;
     if (!rccl().ok) return GCCNMF_ERR_COLLECTIVE;
     ncclUniqueId id;
@@ -71,6 +73,7 @@ int gccnmf_rccl_unique_id(char* id_bytes) {
 }
 
 int gccnmf_rccl_comm_init(const char* id_bytes, int world_size, int rank, void** comm) {
+    GCCNMF_ENTER();
     if (!id_bytes || !comm || world_size < 1 || rank < 0 || rank >= world_size) return GCCNMF_ERR_ARG;
     if (!rccl().ok) return GCCNMF_ERR_COLLECTIVE;
     ncclUniqueId id;
@@ -82,12 +85,14 @@ int gccnmf_rccl_comm_init(const char* id_bytes, int world_size, int rank, void**
 }
 
 int gccnmf_rccl_comm_destroy(void* comm) {
+    GCCNMF_ENTER();
     if (!comm) return GCCNMF_ERR_ARG;
     if (!rccl().ok) return GCCNMF_ERR_COLLECTIVE;
     return rccl().comm_destroy((ncclComm_t)comm) == ncclSuccess ? GCCNMF_OK : GCCNMF_ERR_COLLECTIVE;
 }
 
 int gccnmf_rccl_allreduce(void* comm, float* buf, long count, void* stream) {
+    GCCNMF_ENTER();
     if (!comm || !buf || count < 0) return GCCNMF_ERR_ARG;
     if (!rccl().ok) return GCCNMF_ERR_COLLECTIVE;
     return rccl().all_reduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream) == ncclSuccess
@@ -95,6 +100,7 @@ int gccnmf_rccl_allreduce(void* comm, float* buf, long count, void* stream) {
                : GCCNMF_ERR_COLLECTIVE;
 }
 
-gccnmf_allreduce_fn gccnmf_rccl_allreduce_hook(void) { return &gccnmf_rccl_allreduce; }
+gccnmf_allreduce_fn gccnmf_rccl_allreduce_hook(void) {
+    GCCNMF_ENTER(); return &gccnmf_rccl_allreduce; }
 
 }  // extern "C"

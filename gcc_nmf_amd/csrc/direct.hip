@@ -21,8 +21,6 @@
 #include "direct.h"
 
 #define DIRECT_MAX_DEVICES 64
-extern int gccnmf_tune_ablate;
-extern int gccnmf_tune_direct_depth;
 extern long long* gccnmf_trace_buf;
 extern int gccnmf_trace_blocks;
 
@@ -388,7 +386,6 @@ static size_t direct_lds_bytes(int mb, int nb, int nw) {
     return need > 84 * 1024 ? need : 84 * 1024;
 }
 
-extern int gccnmf_tune_direct_depth;
 template <int MB, int NB, int EPI, int NBUF>
 static int direct_launch_n(const DirectArgs& a, hipStream_t stream) {
     constexpr int NW = 4;
@@ -488,6 +485,7 @@ int gccnmf_direct_launch(DirectArgs a, int epi, int tile, hipStream_t stream) {
 }
 
 extern "C" int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, void* stream) {
+    GCCNMF_ENTER();
     if (!desc || tile < 0) return GCCNMF_ERR_ARG;
     return gccnmf_direct_launch(*desc, epilogue, tile, (hipStream_t)stream);
 }

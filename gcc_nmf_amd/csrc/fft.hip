@@ -333,7 +333,6 @@ __global__ __launch_bounds__(256) void pcm_pack_kernel(const float* __restrict__
     pcm[g * L + m] = make_short2((short)(int)a, (short)(int)b);
 }
 
-extern int gccnmf_tune_fft_r16;     // key 15 (nmf.hip): 1 (default) = up to four butterfly stages per LDS round trip, 0 = one (same bits)
 static inline int fft_ps() { return gccnmf_tune_fft_r16 ? 4 : FFT_NOPAD; }
 static inline size_t fft_rows_bytes(int tb, int n_fft, int ps) { return sizeof(float2) * ((size_t)tb * fft_row_floats2(n_fft, ps) + n_fft / 2); }
 
@@ -375,16 +374,19 @@ static int launch_stft(const void* x, long x_stride, int n_samples, int n_fft, i
 
 int gccnmf_stft_stereo(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int batch, const float* window,
                        const float* twiddle, float* X, float* V, float* CC, void* stream) {
+    GCCNMF_ENTER();
     return launch_stft(x, x_stride, n_samples, n_fft, hop, T, batch, window, twiddle, X, V, CC, false, stream);
 }
 
 int gccnmf_stft_stereo_pcm16(const short* pcm, long frame_stride, int n_samples, int n_fft, int hop, int T, int batch,
                              const float* window, const float* twiddle, float* X, float* V, float* CC, void* stream) {
+    GCCNMF_ENTER();
     return launch_stft(pcm, frame_stride, n_samples, n_fft, hop, T, batch, window, twiddle, X, V, CC, true, stream);
 }
 
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream) {
+    GCCNMF_ENTER();
     const int logN = ilog2_exact(n_fft);
     if (!spec || !window || !twiddle || !y || logN < 6 || logN > 12 || hop < 1 || T < 1 || batch < 1 || nsig < 2 || (nsig & 1))
         return GCCNMF_ERR_ARG;
@@ -436,6 +438,7 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
 
 int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, int batch, int first_sample, int L, float gain,
                       float* y, void* stream) {
+    GCCNMF_ENTER();
     if (!frames || !y || nsig < 1 || n_fft < 2 || hop < 1 || T < 1 || batch < 1 || first_sample < 0 || L < 1 ||
         (long)first_sample + L > (long)n_fft + (long)hop * (T - 1))
         return GCCNMF_ERR_ARG;
@@ -447,6 +450,7 @@ int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, 
 
 int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int nsig, int n_fft, int hop, int T, int first_sample, int L,
                            float gain, float* y, void* stream) {
+    GCCNMF_ENTER();
     if (!frames || !y || nsig < 1 || n_fft < 2 || hop < 1 || T < 1 || halo < 0 || (halo > 0 && !prev) || first_sample < 0 || L < 1 ||
         (long)first_sample + L > (long)n_fft + (long)hop * (halo + T - 1))
         return GCCNMF_ERR_ARG;
@@ -457,6 +461,7 @@ int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int
 }
 
 int gccnmf_pack_pcm16(const float* y, int groups, int L, unsigned int* peak_scratch, short* pcm, void* stream) {
+    GCCNMF_ENTER();
     if (!y || !peak_scratch || !pcm || groups < 1 || L < 1) return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(peak_scratch, 0, sizeof(unsigned int) * groups, s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
@@ -510,6 +515,7 @@ __global__ __launch_bounds__(256) void dft_unpack_kernel(const float2* __restric
 extern "C" {
 
 long gccnmf_dft_workspace_floats(int n_fft, int T, int nsig) {
+    GCCNMF_ENTER();
     if (n_fft < 2 || T < 1 || nsig < 1) return -1;
     GccNmfPitches p = gccnmf_make_pitches(n_fft / 2 + 1, T, 1);
     const long fwd = (long)nsig * ((long)gccnmf_round_up(n_fft, 16) + 2L * p.Fp) * p.Tp;      // framesT | planes
@@ -519,6 +525,7 @@ long gccnmf_dft_workspace_floats(int n_fft, int T, int nsig) {
 
 int gccnmf_stft_dft(const float* x, long x_stride, int n_samples, int n_fft, int hop, int T, int nsig, const float* basis,
                     float* workspace, float* X, void* stream) {
+    GCCNMF_ENTER();
     if (!x || !basis || !workspace || !X || n_fft < 2 || n_fft > 8192 || hop < 1 || T < 1 || nsig < 1) return GCCNMF_ERR_ARG;
     if ((long)(T - 1) * hop + n_fft > n_samples) return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -538,6 +545,7 @@ int gccnmf_stft_dft(const float* x, long x_stride, int n_samples, int n_fft, int
 
 int gccnmf_istft_dft(const float* spec, int nsig, int n_fft, int hop, int T, const float* ibasis, float gain, int center, float* workspace,
                      float* y, void* stream) {
+    GCCNMF_ENTER();
     if (!spec || !ibasis || !workspace || !y || n_fft < 2 || n_fft > 8192 || (n_fft & 1) || hop < 1 || T < 1 || nsig < 1) return GCCNMF_ERR_ARG;
     const int trim = center ? n_fft / 2 : 0;
     const int L = n_fft + hop * (T - 1) - 2 * trim;

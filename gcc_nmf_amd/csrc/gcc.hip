@@ -9,9 +9,6 @@
 // so each stage is ONE launch for the whole batch.
 #include "gemm_ring.h"
 
-extern int gccnmf_tune_ring;            // nmf.hip (gccnmf_set_tuning keys 4 and 2)
-extern int gccnmf_tune_tile_policy;
-extern int gccnmf_tune_dma;             // key 3: throughput tiles stage their operands by LDS-DMA (gemm_dma.h)
 
 // One-shot GEMMs of a launch that cannot fill the chip with 512 x 64 tiles (one mixture alone: 60 of them) take the small-tile ring
 // kernel (128 x 64, gemm_ring.h): 240 workgroups instead of 60 -- reconstruction 191 -> ~40 us, scores 83 -> ~25 us, angular
@@ -226,6 +223,7 @@ extern "C" {
 
 int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T, int D, int batch, float* ang,
                                double* mean_ang, void* stream) {
+    GCCNMF_ENTER();
     if (!CC || !trig || !ang || F < 2 || T < 1 || D < 1 || batch < 1) return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
@@ -250,6 +248,7 @@ int gccnmf_angular_spectrogram(const float* CC, const float* trig, int F, int T,
 
 int gccnmf_pick_tdoa_peaks(const double* mean_ang, int D, int Dp, int S, int batch, int* tdoa_idx, int* status,
                            void* stream) {
+    GCCNMF_ENTER();
     if (!mean_ang || !tdoa_idx || !status || D < 3 || D > 4096 || Dp < D || S < 1 || batch < 1) return GCCNMF_ERR_ARG;
     hipLaunchKernelGGL(pick_peaks_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, mean_ang, D, Dp, S, tdoa_idx, status);
     GCCNMF_CHECK_LAUNCH();
@@ -257,6 +256,7 @@ int gccnmf_pick_tdoa_peaks(const double* mean_ang, int D, int Dp, int S, int bat
 }
 
 long gccnmf_scores_workspace_floats(int F, int T, int S, int batch) {
+    GCCNMF_ENTER();
     if (F < 2 || T < 1 || S < 1 || batch < 1) return -1;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     return (long)batch * p.Fp * S * p.Tp;
@@ -265,6 +265,7 @@ long gccnmf_scores_workspace_floats(int F, int T, int S, int batch) {
 int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* tdoa_idx, const float* W, int F, int T,
                                int K, int D, int S, int batch, float* workspace, float* scores, unsigned char* argmax,
                                void* stream) {
+    GCCNMF_ENTER();
     if (!CC || !trig || !tdoa_idx || !W || !workspace || !scores || F < 2 || T < 1 || K < 1 || D < 1 || S < 1 || S > 255 ||
         batch < 1)
         return GCCNMF_ERR_ARG;
@@ -302,6 +303,7 @@ int gccnmf_target_scores_masks(const float* CC, const float* trig, const int* td
 }
 
 int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, unsigned char* argmax, void* stream) {
+    GCCNMF_ENTER();
     if (!scores || !argmax || K < 1 || T < 1 || S < 1 || S > 255 || batch < 1) return GCCNMF_ERR_ARG;
     GccNmfPitches p = gccnmf_make_pitches(2, T, K);
     hipLaunchKernelGGL(gcc_argmax_kernel, dim3(gccnmf_ceil_div(p.Tp, 1024), p.Kp, batch), dim3(256), 0, (hipStream_t)stream, scores,
@@ -311,6 +313,7 @@ int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, u
 }
 
 int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* stream) {
+    GCCNMF_ENTER();
     if (!X || !CC || F < 2 || T < 1 || batch < 1) return GCCNMF_ERR_ARG;
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     hipLaunchKernelGGL(gcc_coherence_kernel, dim3(gccnmf_ceil_div(T, 256), F, batch), dim3(256), 0, (hipStream_t)stream,
@@ -320,6 +323,7 @@ int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* s
 }
 
 long gccnmf_reconstruct_workspace_floats(int T, int K, int S, int batch) {
+    GCCNMF_ENTER();
     if (T < 1 || K < 1 || S < 1 || batch < 1) return -1;
     GccNmfPitches p = gccnmf_make_pitches(2, T, K);
     return (long)batch * p.Kp * 2 * S * p.Tp;
@@ -327,6 +331,7 @@ long gccnmf_reconstruct_workspace_floats(int T, int K, int S, int batch) {
 
 int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argmax, const float* masks, const float* X,
                        const float* V, int F, int T, int K, int S, int batch, float* workspace, float* spec, void* stream) {
+    GCCNMF_ENTER();
     if (!W || !H || (!argmax && !masks) || !X || !V || !workspace || !spec || F < 2 || T < 1 || K < 1 || S < 1 || batch < 1)
         return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;

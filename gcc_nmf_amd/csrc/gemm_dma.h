@@ -970,10 +970,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 }
 
 // ---- host side: the plan of a launch -----------------------------------------------------------------------------------------
-extern int gccnmf_tune_tail_split;      // key 9
 #ifdef GCCNMF_EXPERIMENTS
-extern int gccnmf_tune_persistent;      // key 18
-extern int gccnmf_tune_prefetch;        // key 19
 unsigned* gccnmf_ticket_block(hipStream_t stream);
 #endif
 

@@ -40,8 +40,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 // run-time tuning knobs (gccnmf_set_tuning); defined in nmf.hip
-extern int gccnmf_tune_ablate;
-extern int gccnmf_tune_exact_div;
 extern long long* gccnmf_trace_buf;
 extern int gccnmf_trace_blocks;
 

@@ -16,119 +16,77 @@
 int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);
 #include "../../include/gccnmf_hip.h"
 
-int gccnmf_tune_ablate = 0;
+#include <atomic>
 #define GCCNMF_SHARED_STREAMS 4
 #define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
                                      // the ring / throughput kernels win anyway: 8 files 41.5 against 41.3 ms, 12 files 61.9 against 59.3)
-int gccnmf_tune_shared_groups = 3;      // key 8: file groups of the shared-dictionary iteration on separate streams
-int gccnmf_tune_tail_split = 1;       // key 9: 1 (default) = the launcher of the throughput tile picks the form (gemm_dma.h): half-height tiles for the files of a
-                                      // partial last round / for outputs of at most 256 rows, a narrow (512 x 32) item for a file's ragged last column tile;
-                                      // 0 = full 512 x 64 tiles only; 2 = every full tile as two narrow halves (tests)
-#ifdef GCCNMF_EXPERIMENTS
-int gccnmf_tune_persistent = 0;       // key 18: 1 = launches of more than 512 items run as 512 resident workgroups that pull items by ticket
-int gccnmf_tune_prefetch = 1;         // key 19: 1 = a resident workgroup requests its next item's first k-tile before the current item's epilogue
-#endif
-int gccnmf_tune_exact_div = 1;     // key 7: 1 (default since round 5) = V / (W.H) of the throughput tile is the IEEE quotient, like numpy.divide in the reference;
-                                   // 0 = v_rcp_f32 + one Newton step (<= 1 ulp off in rare cases).  Measured cost of the exact form: 0.0 % on K1 / K3 (profiles/r05b_*)
-int gccnmf_tune_dma = 1;            // 1 (default): throughput-tile GEMMs stage their operands by LDS-DMA (gemm_dma.h)
-int gccnmf_tune_tile_policy = 0;   // 0 auto, 1 always the throughput tile, 2 always the small-batch tile
-int gccnmf_tune_ring = 1;          // 1 (default): small-batch tiles run on the LDS-DMA ring kernel (gemm_ring.h), 0: register-staged
-int gccnmf_tune_wh_splits = 3;     // single-file split-K: parts of the W.H reduction (1 = unsplit, 2, 4)
-int gccnmf_tune_rht_splits = 4;    //                      parts of the R.H^T reduction (1, 2, 4)
-int gccnmf_tune_direct = 1;        // key 10: 1 (default) = launches that cannot fill the chip take the direct-to-register kernels (direct.hip)
-int gccnmf_tune_direct_tile = 0;   // key 11: 0 = tile by the cost model, 1..8 = that tile for every direct launch (experiments)
-int gccnmf_tune_direct_batch = 4;  // key 12: largest batch that takes the direct path (measured, K = 1024: 4 files 21.8 ms against 25.8 on the ring
-                                   // kernel, 8 files 41.5 / 41.3, 12 files 61.9 / 59.3)
-int gccnmf_tune_fft_r16 = 1;       // key 15: 1 (default) = the offline STFT / iSTFT run up to four radix-2 stages per LDS round trip (fft_core.h)
-int gccnmf_tune_short_updh = 1;    // key 14: 1 (default) = H updates with at most 128 atoms run on the ring kernel's 128 x 64 tiles
-int gccnmf_tune_fused_k34 = 1;     // key 17: short dictionaries (K <= 128) run K3 and K4a as ONE launch of 64-bin slabs, R never written (direct.hip):
-                                   // 0 never, 1 (default) when its whole rounds of 512 workgroups beat the two launches, 2 whenever the shape allows
-int gccnmf_tune_fused_k12 = 1;     // key 16: short dictionaries (K <= 128) run K1 and K2 as ONE launch of column tiles with H resident, R never written (direct.hip):
-                                   // 0 never, 1 (default) when its rounds of 512 workgroups beat the two launches, 2 whenever the shape allows
-int gccnmf_tune_direct_depth = 0;  // key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4)
+// The tuning table (common.h documents the keys): default, lowest and highest value, experiment-only.
+struct GccNmfKnob {
+    int def, lo, hi, experiment;
+};
+static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
+    {0, 0, 0, 1},                       //  0 (unused)
+    {0, 0, 1 << 30, 1},                 //  1 ablate
+    {0, 0, 2, 0},                       //  2 tile_policy
+    {1, 0, 1, 0},                       //  3 dma
+    {1, 0, 1, 1},                       //  4 ring
+    {3, 1, 4, 1},                       //  5 wh_splits
+    {4, 1, 4, 1},                       //  6 rht_splits
+    {1, 0, 1, 0},                       //  7 exact_div: the IEEE quotient since round 5 (measured cost on K1 / K3: 0.0 %, profiles/r05b_kbench_exact_div.txt)
+    {3, 1, GCCNMF_SHARED_STREAMS, 0},   //  8 shared_groups
+    {1, 0, 2, 0},                       //  9 tail_split
+    {1, 0, 1, 0},                       // 10 direct
+    {0, 0, 8, 1},                       // 11 direct_tile
+    {4, 1, GCCNMF_DIRECT_MAX_BATCH, 0}, // 12 direct_batch (measured, K = 1024: 4 files 21.8 ms against 25.8 on the ring kernel, 8 files 41.5 / 41.3)
+    {0, 0, 4, 1},                       // 13 direct_depth (0, 2..4)
+    {1, 0, 1, 1},                       // 14 short_updh
+    {1, 0, 1, 1},                       // 15 fft_r16
+    {1, 0, 2, 0},                       // 16 fused_k12
+    {1, 0, 2, 0},                       // 17 fused_k34
+    {0, 0, 1, 1},                       // 18 persistent
+    {1, 0, 1, 1},                       // 19 prefetch
+};
+static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
+static std::atomic<int> gccnmf_knobs_ready{0};
+static void gccnmf_knobs_init() {
+    static std::mutex mu;
+    if (gccnmf_knobs_ready.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (gccnmf_knobs_ready.load(std::memory_order_relaxed)) return;
+    for (int k = 0; k < GCCNMF_TUNE_KEYS; ++k) gccnmf_knob_value[k].store(gccnmf_knobs[k].def, std::memory_order_relaxed);
+    gccnmf_knobs_ready.store(1, std::memory_order_release);
+}
+static GccNmfTune gccnmf_tune_load() {
+    gccnmf_knobs_init();
+    GccNmfTune t;
+    for (int k = 0; k < GCCNMF_TUNE_KEYS; ++k) t.v[k] = gccnmf_knob_value[k].load(std::memory_order_relaxed);
+    return t;
+}
+thread_local GccNmfTune gccnmf_tune = gccnmf_tune_load();
+static thread_local int gccnmf_call_depth = 0;
+GccNmfCall::GccNmfCall() {
+    if (gccnmf_call_depth++ == 0) gccnmf_tune = gccnmf_tune_load();      // one snapshot per outermost library call
+}
+GccNmfCall::~GccNmfCall() { --gccnmf_call_depth; }
 long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
 extern "C" {
-int gccnmf_version(void) { return 105; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT,
+int gccnmf_version(void) {
+    GCCNMF_ENTER(); return 105; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT,
                                            // fused short-dictionary launches (tuning keys 16 / 17, gccnmf_klnmf_plan, GCCNMF_FLAG_GROUPS)
 
 int gccnmf_set_tuning(int key, int value) {
-    if (key == 1) {
-        gccnmf_tune_ablate = value;
-        return GCCNMF_OK;
-    }
-    if (key == 2 && value >= 0 && value <= 2) {
-        gccnmf_tune_tile_policy = value;
-        return GCCNMF_OK;
-    }
-    if (key == 3) {
-        gccnmf_tune_dma = value ? 1 : 0;
-        return GCCNMF_OK;
-    }
-    if (key == 4) {
-        gccnmf_tune_ring = value ? 1 : 0;
-        return GCCNMF_OK;
-    }
-    if (key == 9 && value >= 0 && value <= 2) {
-        gccnmf_tune_tail_split = value;
-        return GCCNMF_OK;
-    }
-#ifdef GCCNMF_EXPERIMENTS
-    if (key == 18 && (value == 0 || value == 1)) {
-        gccnmf_tune_persistent = value;
-        return GCCNMF_OK;
-    }
-    if (key == 19 && (value == 0 || value == 1)) {
-        gccnmf_tune_prefetch = value;
-        return GCCNMF_OK;
-    }
+    GCCNMF_ENTER();
+    gccnmf_knobs_init();
+    if (key < 1 || key >= GCCNMF_TUNE_KEYS) return GCCNMF_ERR_ARG;
+    const GccNmfKnob& k = gccnmf_knobs[key];
+#ifndef GCCNMF_EXPERIMENTS
+    if (k.experiment) return GCCNMF_ERR_ARG;                 // the product build carries none of the code these select
 #endif
-    if (key == 8 && value >= 1 && value <= GCCNMF_SHARED_STREAMS) {
-        gccnmf_tune_shared_groups = value;
-        return GCCNMF_OK;
-    }
-    if (key == 7 && (value == 0 || value == 1)) {
-        gccnmf_tune_exact_div = value;
-        return GCCNMF_OK;
-    }
-    if (key == 10 && (value == 0 || value == 1)) {
-        gccnmf_tune_direct = value;
-        return GCCNMF_OK;
-    }
-    if (key == 11 && value >= 0 && value <= 8) {
-        gccnmf_tune_direct_tile = value;
-        return GCCNMF_OK;
-    }
-    if (key == 15 && (value == 0 || value == 1)) {
-        gccnmf_tune_fft_r16 = value;
-        return GCCNMF_OK;
-    }
-    if (key == 14 && (value == 0 || value == 1)) {
-        gccnmf_tune_short_updh = value;
-        return GCCNMF_OK;
-    }
-    if (key == 16 && value >= 0 && value <= 2) {
-        gccnmf_tune_fused_k12 = value;
-        return GCCNMF_OK;
-    }
-    if (key == 17 && value >= 0 && value <= 2) {
-        gccnmf_tune_fused_k34 = value;
-        return GCCNMF_OK;
-    }
-    if (key == 13 && (value == 0 || (value >= 2 && value <= 4))) {
-        gccnmf_tune_direct_depth = value;
-        return GCCNMF_OK;
-    }
-    if (key == 12 && value >= 1 && value <= GCCNMF_DIRECT_MAX_BATCH) {
-        gccnmf_tune_direct_batch = value;
-        return GCCNMF_OK;
-    }
-    if ((key == 5 || key == 6) && value >= 1 && value <= 4) {
-        (key == 5 ? gccnmf_tune_wh_splits : gccnmf_tune_rht_splits) = value;
-        return GCCNMF_OK;
-    }
-    return GCCNMF_ERR_ARG;
+    if (value < k.lo || value > k.hi || (key == 13 && value == 1)) return GCCNMF_ERR_ARG;
+    gccnmf_knob_value[key].store(value, std::memory_order_relaxed);      // takes effect at the next library call (GccNmfCall)
+    return GCCNMF_OK;
 }
 
 }  // extern "C"
@@ -172,12 +130,14 @@ unsigned* gccnmf_ticket_block(hipStream_t stream) {
 
 extern "C" {
 int gccnmf_debug_set_trace(long long* buf, int blocks) {
+    GCCNMF_ENTER();
     gccnmf_trace_buf = buf;
     gccnmf_trace_blocks = buf ? blocks : 0;
     return GCCNMF_OK;
 }
 
 int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
+    GCCNMF_ENTER();
     if (F < 2 || T < 1 || K < 1 || !Fp || !Kp || !Np || !Tp) return GCCNMF_ERR_ARG;
     GccNmfPitches p = gccnmf_make_pitches(F, T, K);
     *Fp = p.Fp;
@@ -864,6 +824,7 @@ extern "C" {
 // GCCNMF_SPLITS x max(Fp*Np, Fp*Kp) (W.H parts and R.H^T parts use the same memory at different stages) + GCCNMF_SPLITS x Kp
 // | (batch <= GCCNMF_DIRECT_MAX_BATCH) the transposed copies of the direct path: Wt [batch][Kp][Fp], Ht [batch][Np][Kp], Rt [batch][Np][Fp]
 long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
+    GCCNMF_ENTER();
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
     long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
@@ -961,6 +922,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
 // Which launches gccnmf_klnmf would use for this problem under the current tuning: bit 0 the direct latency kernels, bit 1 the fused
 // K1 + K2 launch, bit 2 the fused K3 + K4a slab launch (benchmarks and tests name the kernel they time by this).
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
+    GCCNMF_ENTER();
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     const NmfGeom g = make_geom(F, N, K);
     return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht_files(g, batch, flags) > 0 ? 4 : 0);
@@ -968,12 +930,14 @@ int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
 
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
                        float sparsity_alpha, float epsilon, int flags, int stage, void* stream) {
+    GCCNMF_ENTER();
     if (!V || !W || !H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
     return klnmf_stage(stage, V, W, H, workspace, make_geom(F, N, K), batch, sparsity_alpha, epsilon, flags, (hipStream_t)stream);
 }
 
 int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch, int iterations,
                  float sparsity_alpha, float epsilon, int flags, void* stream) {
+    GCCNMF_ENTER();
     if (!V || !W || !H || !workspace || F < 2 || N < 1 || K < 1 || batch < 1 || iterations < 0) return GCCNMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     NmfGeom g = make_geom(F, N, K);
@@ -1204,24 +1168,28 @@ static float* legacy_vec(const SharedShard& sh) {
 }
 
 long gccnmf_klnmf_shared_workspace_floats(int F, int N, int K, int batch) {
+    GCCNMF_ENTER();
     if (!shared_shard_ok(F, N, K, batch, 0)) return -1;
     NmfGeom g = make_geom(F, N, K);
     return (long)batch * (g.sV + g.sU + g.Kp) + (shared_single_file_layout(g, batch, 0) ? shared_split_floats(g) : 0) + 2L * g.Kp;
 }
 
 long gccnmf_klnmf_shared_shard_workspace_floats(int F, int N, int K, int batch, int ld) {
+    GCCNMF_ENTER();
     if (!shared_shard_ok(F, N, K, batch, ld)) return -1;
     NmfGeom g = make_geom(F, N, K);
     return shared_r_floats(g, batch, ld) + (long)batch * (g.sU + g.Kp) + (shared_single_file_layout(g, batch, ld) ? shared_split_floats(g) : 0);
 }
 
 long gccnmf_klnmf_shared_partial_floats(int F, int K) {
+    GCCNMF_ENTER();
     if (F < 2 || K < 1) return -1;
     NmfGeom g = make_geom(F, 1, K);
     return g.sU + g.Kp;
 }
 
 int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, int K, int batch, void* stream) {
+    GCCNMF_ENTER();
     if (!W || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
     float* vec = legacy_vec(sh);
@@ -1230,6 +1198,7 @@ int gccnmf_klnmf_shared_begin(const float* W, float* workspace, int F, int N, in
 
 int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* workspace, float* partial, int F, int N,
                                int K, int batch, float sparsity_alpha, float epsilon, void* stream) {
+    GCCNMF_ENTER();
     if (!V || !W || !H || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(V, H, workspace, F, N, K, batch, 0);
     float* vec = legacy_vec(sh);
@@ -1237,6 +1206,7 @@ int gccnmf_klnmf_shared_step_a(const float* V, const float* W, float* H, float* 
 }
 
 int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial, int F, int N, int K, int batch, void* stream) {
+    GCCNMF_ENTER();
     if (!W || !workspace || !partial || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, nullptr, workspace, F, N, K, batch, 0);
     float* vec = legacy_vec(sh);
@@ -1244,6 +1214,7 @@ int gccnmf_klnmf_shared_step_b(float* W, float* workspace, const float* partial,
 }
 
 int gccnmf_klnmf_shared_finish(float* H, float* workspace, int F, int N, int K, int batch, void* stream) {
+    GCCNMF_ENTER();
     if (!H || !workspace || !shared_shard_ok(F, N, K, batch, 0)) return GCCNMF_ERR_ARG;
     SharedShard sh = make_shard(nullptr, H, workspace, F, N, K, batch, 0);
     float* vec = legacy_vec(sh);
@@ -1273,6 +1244,7 @@ struct SharedRunGuard {
 int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, float* W, float* partial, float* vec, int F, int K,
                             int iterations, float sparsity_alpha, float epsilon, gccnmf_allreduce_fn allreduce, void* allreduce_ctx,
                             void* stream) {
+    GCCNMF_ENTER();
     if (nshards < 0 || nshards > GCCNMF_MAX_SHARDS || (nshards && !shards) || !W || !partial || !vec || F < 2 || K < 1 || iterations < 0)
         return GCCNMF_ERR_ARG;
     SharedRunGuard guard;
@@ -1300,6 +1272,7 @@ int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, floa
 }
 
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
+    GCCNMF_ENTER();
     if (!scratch || blocks < 1 || iters < 1) return GCCNMF_ERR_ARG;
     hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
     GCCNMF_CHECK_LAUNCH();
@@ -1307,6 +1280,7 @@ int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) 
 }
 
 int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items) {
+    GCCNMF_ENTER();
     if (M < 1 || N < 1 || batch < 1 || !plan || (max_items > 0 && !items)) return -1;
     GemmArgs a = {};
     a.M = M; a.N = N; a.batch = batch; a.xcd_affine = xcd_affine; a.concurrent = concurrent;
@@ -1331,6 +1305,7 @@ int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurre
 int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, int Kd, int lda, int ldb, int ldc,
                       int a_clamp, int b_clamp, int layout, int batch, long sA, long sB, long sC, const float* bscale,
                       float* rowsumB, void* stream) {
+    GCCNMF_ENTER();
     GemmArgs a = {};
     a.A = A; a.sA = sA; a.lda = lda; a.a_clamp = a_clamp;
     a.B = B; a.sB = sB; a.ldb = ldb; a.b_clamp = b_clamp;

@@ -580,6 +580,7 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                                int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp, int numTDOAHistory,
                                int target_mode, int separation_enabled, int localization_enabled, int localization_window,
                                int frames_mode_bits, int numHUpdates, int out_delay_blocks, void* stream) {
+    GCCNMF_ENTER();
     // frames_mode_bits: 1 = frames mode (above); 2 = leave the localisation kernel out of this call; 4 = ONLY the localisation kernel
     // (2 then 4 = the same work in two calls, so that a host can fetch block_out before the tracking update has run)
     const int frames_mode = frames_mode_bits & 1;
@@ -678,6 +679,7 @@ int gccnmf_rt_process_block(const float* block_in, float* block_out, float* in_r
                             const float* twiddle, int windowSize, int hopSize, int blockSize, int K, int Kp, int D, int Dp,
                             int numTDOAHistory, int target_mode, int separation_enabled, int localization_enabled,
                             int localization_window, int frames_mode, void* stream) {
+    GCCNMF_ENTER();
     return gccnmf_rt_process_block_ll(block_in, block_out, in_ring, out_ring, X, Y, C, HMask, argmaxTDOA, tfMask, hist, hist_pos, target,
                                       gccphat, W, cosT, sinT, window, window, twiddle, nullptr, nullptr, nullptr, windowSize, hopSize,
                                       blockSize, K, Kp, D, Dp, numTDOAHistory, target_mode, separation_enabled, localization_enabled,

@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--K', type=int, default=1024)
     ap.add_argument('--stage', type=int, default=1)
     ap.add_argument('--dump', default='')
+    ap.add_argument('--repeat', type=int, default=0, help='launch the stage this many times right before the traced launch (back-to-back launches of one kernel)')
     ap.add_argument('--probe', action='store_true', help='library built with -DGEMM_DMA_PROBE: per-phase cycles of the k-tile')
     a = ap.parse_args()
     import torch
@@ -47,6 +48,8 @@ def main():
     torch.cuda.synchronize()
     nblk = 16384
     trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
+    for _ in range(a.repeat):
+        stage(a.stage)
     lib.gccnmf_debug_set_trace(_ptr(trace), nblk)
     stage(a.stage)
     torch.cuda.synchronize()
@@ -54,7 +57,7 @@ def main():
     t_all = trace.cpu().numpy()
     tiles = {1: 1 * (g.Np // 64), 3: 1 * (g.Np // 64), 2: -(-K // 512) * (g.Np // 64), 4: -(-K // 64)}[a.stage]
     grid = 8 * (-(-B // 8)) * tiles
-    t = t_all[:grid]
+    t = t_all[:max(grid, int(np.nonzero(t_all[:, 0])[0].max()) + 1)] if not a.probe else t_all[:grid]
     if a.probe:
         pr = t_all[grid:5 * grid, :7].reshape(grid, 4, 7).astype(np.float64)
         nkt = {1: K // 16, 3: K // 16, 2: (F - 1) // 16, 4: g.Np // 16}[a.stage]
