@@ -490,13 +490,14 @@ extern "C" int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, 
     return gccnmf_direct_launch(*desc, epilogue, tile, (hipStream_t)stream);
 }
 
+#include "gemm_mfma.h"
+#ifdef GCCNMF_EXPERIMENTS
 // ---- experiment: the THROUGHPUT tile without LDS (round 4) ------------------------------------------------------------------
 // The same idea at batch scale, for GEMMs whose operands are both reduction-major already (the H update: A = W [f][k], B = R [f][n]):
 // a 512 x 64 workgroup tile as in gemm_dma.h (4 waves x 128 x 64, v_mfma_f32_32x32x2_f32), but every wave fetches its own 128 rows
 // of A (one 16-byte load per lane and k-step pair = four interleaved 32-row blocks) and the tile's 64 columns of B straight from
 // L1 / L2 into registers: no LDS-DMA, no fragment reads, no barrier -- the four waves never synchronise.  B is fetched by all four
 // waves of a workgroup (the second to fourth hit the CU's vector L1).  Reached through gccnmf_debug_gemm (layout bit 32) for timing.
-#include "gemm_mfma.h"
 template <int NBUF>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_stream_kernel(const GemmArgs p) {
     constexpr int BM = 512, BN = 64, RW = 128, CK = 8;         // chunk = 8 reduction rows = 4 MFMA steps of 2
@@ -613,6 +614,7 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream) {
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
+#endif  // GCCNMF_EXPERIMENTS
 
 // ---- K1 and K2 of one KL-NMF iteration in ONE launch, for short dictionaries (round 4) ----------------------------------------------
 //   R = V / (W . (s*H))   then   H = (s*H) * (W^T . R) / (colsum W + alpha + eps)            (gccNMFFunctions.py:76)

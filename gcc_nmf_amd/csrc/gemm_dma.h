@@ -252,30 +252,39 @@ struct GemmEpiloguePair {
         const int lo = 4 * (4 * hh * p.ldc + col_a);
         const int ro = 4 * row_u * p.ldc, rstep = 4 * p.ldc;
         const gemm_i32x4 C = gemm_buffer_rsrc(p.C + file * p.sC, cb);
-        // One column block at a time, every value computed right in front of its store and the order pinned: left to itself the
-        // scheduler either interleaves them like this or computes all 32 values first and bursts the stores behind them -- the burst form
-        // is ~1 % of the whole launch slower (K1 0.660 against 0.654 ms, round 5), and which one it picks flips with unrelated edits.
+        // One column block at a time: its 16 values first -- independent chains the scheduler interleaves (an IEEE division is an
+        // 11-instruction dependent chain: computed one element at a time in front of its store, the epilogue took 28 us instead of 17
+        // beside a neighbour's main loop, profiles/r05e_ktrace_*; all 32 at once spill) -- then its 16 stores as one burst.  The division
+        // mode is ONE wave-uniform branch around two unrolled loops, not a branch per element.
         auto column = [&](const f32x16& acc, const float (&x)[16], const float b, const int lane_off) {
+            float u[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                gemm_f32x4 tav = {0.f, 0.f, 0.f, 0.f}, gv = tav;
-                if (EPI == EPI_STORE || EPI == EPI_UPDH) tav = *(const gemm_f32x4*)(s_rowvec + tile_row + 8 * g + 4 * hh);
-                if (EPI == EPI_UPDH) gv = *(const gemm_f32x4*)(s_rowvec + BM + tile_row + 8 * g + 4 * hh);
+            for (int r = 0; r < 16; ++r) u[r] = acc[r];
+            if (EPI == EPI_STORE || EPI == EPI_UPDH) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * g + i;
-                    float u = acc[r];
-                    if (EPI == EPI_STORE || EPI == EPI_UPDH) u = fmaf(tav[i], b, u);     // last reduction index as one fmaf per element, in chain order (the final k)
-                    if (EPI == EPI_DIV) {
-                        if (p.exact_div) u = x[r] / u;          // tuning key 7: the IEEE quotient, as the reference's numpy.divide (wave-uniform branch)
-                        else u = gemm_div_fast(x[r], u);
-                    } else if (EPI == EPI_UPDH) {
-                        u = (x[r] * u) * gv[i];
+                for (int g = 0; g < 4; ++g) {
+                    const gemm_f32x4 tav = *(const gemm_f32x4*)(s_rowvec + tile_row + 8 * g + 4 * hh);
+                    gemm_f32x4 gv = {1.f, 1.f, 1.f, 1.f};
+                    if (EPI == EPI_UPDH) gv = *(const gemm_f32x4*)(s_rowvec + BM + tile_row + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        u[r] = fmaf(tav[i], b, u[r]);          // last reduction index as one fmaf per element, in chain order (the final k)
+                        if (EPI == EPI_UPDH) u[r] = (x[r] * u[r]) * gv[i];
                     }
-                    gemm_buffer_store(u, C, lane_off, ro + ((r & 3) + 8 * (r >> 2)) * rstep, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            if (EPI == EPI_DIV) {
+                if (p.exact_div) {          // tuning key 7 (default): the IEEE quotient, as the reference's numpy.divide
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) u[r] = x[r] / u[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) u[r] = gemm_div_fast(x[r], u[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gemm_buffer_store(u[r], C, lane_off, ro + ((r & 3) + 8 * (r >> 2)) * rstep, 0);
         };
         if (oka) column(acc_a, xa, ba, lo);
         if (okb) column(acc_b, xb, bb, lo + 128);

@@ -13,11 +13,14 @@
 #include <mutex>
 #include "gemm_ring.h"
 #include "direct.h"
-int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);
+#ifdef GCCNMF_EXPERIMENTS
+int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);       // the LDS-free throughput tile (direct.hip)
+#endif
 #include "../../include/gccnmf_hip.h"
 
 #include <atomic>
 #define GCCNMF_SHARED_STREAMS 4
+#define GCCNMF_SPLITS 4           // parts of the round-3 single-file split-K (experiment builds); the workspace layout keeps room for them
 #define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
                                      // the ring / throughput kernels win anyway: 8 files 41.5 against 41.3 ms, 12 files 61.9 against 59.3)
 // The tuning table (common.h documents the keys): default, lowest and highest value, experiment-only.
@@ -574,6 +577,7 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, true>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_UPDW, false>(a, s);
 }
 
+#ifdef GCCNMF_EXPERIMENTS
 // ------------------------------------------------------------------------------------------
 // One file alone (BASELINE config 2 as a single mixture): split-K
 // ------------------------------------------------------------------------------------------
@@ -582,7 +586,6 @@ static int launch_rht_update_w(const NmfGeom& g, const float* R, const float* H,
 // (operand base + part * length, partial outputs side by side): W.H over the atoms, R.H^T over the columns.  The parts
 // are added in ascending order by the consumer -- nmf_div_partials_kernel (R = V / sum) and nmf_update_w_kernel -- so the
 // result does not depend on scheduling.  Zero padding makes the parts equal: Kp and Np are multiples of 64.
-#define GCCNMF_SPLITS 4
 
 // R[f][n] = V[f][n] / (P_0 + P_1 + ... )[f][n] on the valid F x N region only (R's padding must stay zero)
 // one float4 per thread; columns >= N of the last float4 are written as 0 (not 0/0)
@@ -661,6 +664,8 @@ static int launch_rht_split(const NmfGeom& g, const float* R, const float* H, fl
         return g.tail ? gccnmf_launch_gemm_ring<true, true, EPI_STORE, true>(a, s) : gccnmf_launch_gemm_ring<true, true, EPI_STORE, false>(a, s);
     return g.tail ? gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, true, 1>(a, s) : gccnmf_launch_gemm<4, 1, true, true, EPI_STORE, false, 1>(a, s);
 }
+
+#endif  // GCCNMF_EXPERIMENTS (single-file split-K)
 
 // ------------------------------------------------------------------------------------------
 // The direct path (csrc/direct.hip): launches that cannot fill the chip -- one mixture alone, the shape behind the reference's
@@ -872,8 +877,12 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             default: return GCCNMF_ERR_ARG;
         }
     }
-    const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);
+#ifdef GCCNMF_EXPERIMENTS
+    const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);      // the round-3 latency path: one file's reductions as parts
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
+#else
+    constexpr bool split_wh = false, split_rht = false;
+#endif
     const int xcd = ((flags & 1) ? 0 : 1) | ((flags & 4) ? 2 : 0);      // bit 1: another file group's launches run beside these
     const int vec_grid = batch * (g.Kp / 16);
     switch (stage) {
@@ -884,7 +893,9 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
             break;
         case 1:
             if (fused12) return launch_wh_updh(g, V, W, H, hscale, colsumW, alpha, eps, batch, s);                         // K1 + K2
+#ifdef GCCNMF_EXPERIMENTS
             if (split_wh) return launch_wh_div_split(g, V, W, H, hscale, parts, R, s);
+#endif
             return launch_wh_div(g, V, W, g.sW, H, hscale, g.Kp, R, batch, xcd, s);
         case 2:
             if (fused12) return GCCNMF_OK;                                                                             // done by stage 1
@@ -895,13 +906,17 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
                 if (rc || !rest34) return rc;
                 return launch_wh_div(g, V + head34 * g.sV, W + head34 * g.sW, g.sW, H + head34 * g.sH, nullptr, 0, R + head34 * g.sV, rest34, xcd, s);
             }
+#ifdef GCCNMF_EXPERIMENTS
             if (split_wh) return launch_wh_div_split(g, V, W, H, nullptr, parts, R, s);
+#endif
             return launch_wh_div(g, V, W, g.sW, H, nullptr, 0, R, batch, xcd, s);
         case 4:
             if (fused34)                                                                                               // done by stage 3 ...
                 return rest34 ? launch_rht(g, R + head34 * g.sV, H + head34 * g.sH, U + head34 * g.sU, rowsumH + (long)head34 * g.Kp, rest34, xcd, s)
                               : GCCNMF_OK;                                                                             // ... but for the rest
+#ifdef GCCNMF_EXPERIMENTS
             if (split_rht) return launch_rht_split(g, R, H, parts, rowsum_parts, s);
+#endif
             if (can_fuse_w_update(g, batch) && !(flags & 2)) return launch_rht_update_w(g, R, H, W, colsumW, hscale, batch, xcd, s);
             return launch_rht(g, R, H, U, rowsumH, batch, xcd, s);
         case 5:
@@ -980,8 +995,12 @@ static bool shared_shard_ok(int F, int N, int K, int batch, int ld) {
 // csrc/nmf.hip "One file alone") instead of 64-80 workgroup launches with 64-78-step chains.
 static bool shared_single_file_layout(const NmfGeom& g, int batch, int ld) { return batch == 1 && (ld == 0 || ld == g.Np); }   // sizes the scratch
 static bool shared_latency_shard(const NmfGeom& g, int batch, int ld) {                                                        // decides per call
+#ifdef GCCNMF_EXPERIMENTS
     return shared_single_file_layout(g, batch, ld) && single_file_split(g, 1, g.Kp, gccnmf_tune_wh_splits) &&
            single_file_split(g, 1, g.Np, gccnmf_tune_rht_splits);
+#else
+    return false;           // the product's latency path is the direct one (sh.direct); the split-K launches are an experiment build's
+#endif
 }
 static long shared_split_floats(const NmfGeom& g) { return GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp) + direct_floats(g, 1); }
 
@@ -1075,12 +1094,14 @@ static int shared_gemms(const SharedShard& sh, const float* W, const float* cols
         if ((rc = direct_wh_div(g, sh.d, sh.V, W, sh.H, nullptr, sh.R, true, 1, s))) return rc;
         return direct_rht(g, sh.d, sh.R, sh.Upart, sh.rowsum_part, 1, s);
     }
-    if (sh.latency) {                           // one file alone: the split-K launches of the latency path
+#ifdef GCCNMF_EXPERIMENTS
+    if (sh.latency) {                           // one file alone: the split-K launches of the round-3 latency path
         if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, hscale, sh.parts, sh.R, s))) return rc;
         if ((rc = launch_update_h(g, W, 0, sh.R, sh.H, hscale, 0, colsumW, 0, alpha, eps, 1, 0, s))) return rc;
         if ((rc = launch_wh_div_split(g, sh.V, W, sh.H, nullptr, sh.parts, sh.R, s))) return rc;
         return launch_rht_split(g, sh.R, sh.H, sh.parts, sh.rowsum_parts, s);
     }
+#endif
     // files are independent inside K1-K3 and per file inside K4a: keep every tile of a file on one XCD (its H / R panels are shared
     // through that XCD's L2), exactly as the per-file-dictionary path does
     if ((rc = launch_wh_div(g, sh.V, W, 0, sh.H, hscale, 0, sh.R, sh.batch, xcd, s))) return rc;
@@ -1323,7 +1344,11 @@ int gccnmf_debug_gemm(const float* A, const float* B, float* C, int M, int N, in
     a.rowsumB = rowsumB; a.s_rowsumB = N;
     a.C = C; a.sC = sC; a.ldc = ldc;
     hipStream_t s = (hipStream_t)stream;
-    if (layout & 32) return (layout & 31) ? GCCNMF_ERR_ARG : gccnmf_launch_gemm_stream(a, s);      // experiment: the LDS-free throughput tile (direct.hip)
+#ifdef GCCNMF_EXPERIMENTS
+    if (layout & 32) return (layout & 31) ? GCCNMF_ERR_ARG : gccnmf_launch_gemm_stream(a, s);      // the LDS-free throughput tile (direct.hip)
+#else
+    if (layout & 32) return GCCNMF_ERR_UNSUPPORTED;
+#endif
     const bool wide = layout & 8;
     if (!wide && gccnmf_tune_dma) {       // the throughput tile's default staging path (tuning key 3)
         switch (layout & 3) {
