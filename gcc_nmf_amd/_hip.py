@@ -86,16 +86,20 @@ SIGNATURES = {
                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'gccnmf_istft_ola': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
                                  c_void_p, c_void_p, c_void_p]),
-    'gccnmf_ola_frames': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'gccnmf_ola_frames_halo': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     'gccnmf_rt_process_block': (c_int, [c_void_p] * 19 + [c_int] * 13 + [c_void_p]),
     'gccnmf_rt_process_block_ll': (c_int, [c_void_p] * 23 + [c_int] * 15 + [c_void_p]),
     'gccnmf_gemm_direct': (c_int, [ctypes.POINTER(DirectGemm), c_int, c_int, c_void_p]),
-    'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),
-    'gccnmf_debug_mfma_peak': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'gccnmf_debug_gemm_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P_INT, P_INT, c_int]),
     'gccnmf_debug_gemm': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p]),
+}
+
+
+# entry points of the lab build only (make -C gcc_nmf_amd/csrc EXPERIMENTS=1 -> libgccnmf_hip_exp.so; `#ifdef GCCNMF_EXPERIMENTS` in the header)
+EXPERIMENT_SIGNATURES = {
+    'gccnmf_debug_set_trace': (c_int, [c_void_p, c_int]),
+    'gccnmf_debug_mfma_peak': (c_int, [c_void_p, c_int, c_int, c_void_p]),
 }
 
 
@@ -128,6 +132,11 @@ def lib():
             raise HipLibraryError('%s does not export %s (stale build? re-run make -C gcc_nmf_amd/csrc)' % (LIB_PATH, name))
         fn.restype = restype
         fn.argtypes = argtypes
+    for name, (restype, argtypes) in EXPERIMENT_SIGNATURES.items():
+        fn = getattr(handle, name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
     # A/B runs without code changes: GCCNMF_TUNE="9=2,8=1" applies gccnmf_set_tuning(key, value) pairs at load time
     for kv in filter(None, os.environ.get('GCCNMF_TUNE', '').split(',')):
         key, value = [int(v) for v in kv.split('=')]

@@ -436,18 +436,6 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
     return GCCNMF_OK;
 }
 
-int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, int batch, int first_sample, int L, float gain,
-                      float* y, void* stream) {
-    GCCNMF_ENTER();
-    if (!frames || !y || nsig < 1 || n_fft < 2 || hop < 1 || T < 1 || batch < 1 || first_sample < 0 || L < 1 ||
-        (long)first_sample + L > (long)n_fft + (long)hop * (T - 1))
-        return GCCNMF_ERR_ARG;
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(gccnmf_ceil_div(L, 256), nsig, batch), dim3(256), 0, (hipStream_t)stream, frames, n_fft, hop, T,
-                       L, first_sample, gain, y, (const float*)nullptr, 0);
-    GCCNMF_CHECK_LAUNCH();
-    return GCCNMF_OK;
-}
-
 int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int nsig, int n_fft, int hop, int T, int first_sample, int L,
                            float gain, float* y, void* stream) {
     GCCNMF_ENTER();

@@ -57,6 +57,18 @@ __device__ __forceinline__ void gemm_dma16_lanes(const float* wave_uniform_base,
                  : "memory");
 }
 
+// The same with a RUN-TIME wave-uniform lane mask (an SGPR pair): a mask of 0 makes the piece a no-op without a branch around it -- the
+// side chunks of a k-tile (tail row of A, row scale of B) belong to wave 0 only, and a taken scalar branch per k-tile in the other
+// three waves is dearer than five scalar instructions in all four.
+__device__ __forceinline__ void gemm_dma16_masked(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr,
+                                                  unsigned long long wave_uniform_mask) {
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_wave_byte_addr), "s"(wave_uniform_mask)
+                 : "memory");
+}
+
 __device__ __forceinline__ int gemm_swz(int row) { return (row >> 2) & 3; }
 
 // The thread index through an asm statement the compiler cannot see through: values derived from it are recomputed where they are
@@ -483,6 +495,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     const float* __restrict__ B = nullptr;
     const float* __restrict__ bscale = nullptr;
     const float* __restrict__ tail_src = nullptr;
+    const float* __restrict__ scale_src = nullptr;
+    unsigned long long tail_mask = 0, scale_mask = 0;                 // lane masks of wave 0's side-chunk pieces (0 = no-op)
     bool wave_active = false, do_tail = false, do_rowsum = false;
     unsigned offA[NA], offB = 0;                                       // per-lane source offsets (bytes from the wave-uniform k-tile origin) of this wave's DMA pieces
     auto take_item = [&](const int ticket) -> bool {
@@ -502,6 +516,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         do_tail = TAIL && (tm == 0);
         do_rowsum = B_KC && (p.rowsumB != nullptr || EPI == EPI_UPDW) && (tm == 0);
         tail_src = A + (long)p.tail_row * p.lda;
+        tail_mask = (wave == 0 && do_tail) ? 0x0full : 0ull;
+        scale_mask = (wave == 0 && bscale != nullptr) ? 0xf0ull : 0ull;
+        scale_src = bscale != nullptr ? bscale : A;              // (never dereferenced under a zero mask; kept a valid address anyway)
         return true;
     };
     auto set_offsets = [&](const int lane) {                           // this wave's DMA source offsets for the current item
@@ -546,12 +563,10 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         } else if (piece == NA) {
             gemm_dma16(B + (B_KC ? (long)kt * BK : (long)kt * BK * p.ldb), offB, lds0 + 4 * (buf * SBUF + SA + wave * 256));
         } else {
-            if (TAIL || SCALE) {
-                if (wave == 0) {                                   // wave-uniform: scalar branches only
-                    const unsigned dst = lds0 + 4 * (buf * SBUF + SA + SB);
-                    if (TAIL && do_tail) gemm_dma16_lanes<0x0fu>(tail_src + kt * BK, side_off, dst);
-                    if (SCALE && bscale != nullptr) gemm_dma16_lanes<0xf0u>(bscale + kt * BK, side_off, dst);
-                }
+            if (TAIL || SCALE) {                                   // wave 0's lanes 0-3 / 4-7; every other wave (and a tile without the chunk): mask 0
+                const unsigned dst = lds0 + 4 * (buf * SBUF + SA + SB);
+                if (TAIL) gemm_dma16_masked(tail_src + kt * BK, side_off, dst, tail_mask);
+                if (SCALE) gemm_dma16_masked(scale_src + kt * BK, side_off, dst, scale_mask);
             }
         }
     };
@@ -607,21 +622,19 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             b1.read(lds + oB1);
         }
         if (SCALE) sc1 = gemm_lds_read_b128<4 * (SA + SB + BK) + 32>(lds + 16 * hh);
+        // (tail row / row sums: read and accumulated by every workgroup of an instantiation that has them -- a tile that does not need
+        // them ignores the result; no scalar branch per k-tile)
         if (TAIL) {
-            if (do_tail) {
-                t4 = gemm_lds_read_b128<4 * (SA + SB)>(lds + 16 * tg);
-                if (B_KC) {
-                    tb4 = gemm_lds_read_b128<0>(lds + oTB);
-                } else {
-                    tbxy = gemm_lds_read2_b32<0 * BN, 1 * BN>(lds + oTB);      // rows 4g, 4g+1 of column j (BN dwords apart)
-                    tbzw = gemm_lds_read2_b32<2 * BN, 3 * BN>(lds + oTB);
-                    if (SCALE) ts4 = gemm_lds_read_b128<4 * (SA + SB + BK)>(lds + 16 * tg);
-                }
+            t4 = gemm_lds_read_b128<4 * (SA + SB)>(lds + 16 * tg);
+            if (B_KC) {
+                tb4 = gemm_lds_read_b128<0>(lds + oTB);
+            } else {
+                tbxy = gemm_lds_read2_b32<0 * BN, 1 * BN>(lds + oTB);      // rows 4g, 4g+1 of column j (BN dwords apart)
+                tbzw = gemm_lds_read2_b32<2 * BN, 3 * BN>(lds + oTB);
+                if (SCALE) ts4 = gemm_lds_read_b128<4 * (SA + SB + BK)>(lds + 16 * tg);
             }
         }
-        if (B_KC) {
-            if (do_rowsum) rs4 = gemm_lds_read_b128<0>(lds + oRS);
-        }
+        if (B_KC) rs4 = gemm_lds_read_b128<0>(lds + oRS);
     };
     auto wait_group0 = [&]() {
         gemm_wait_lds();
@@ -771,16 +784,12 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             }
         }
         if (TAIL) {
-            if (do_tail) {
-                tail_acc = fmaf(t4.x, tb4.x, tail_acc);
-                tail_acc = fmaf(t4.y, tb4.y, tail_acc);
-                tail_acc = fmaf(t4.z, tb4.z, tail_acc);
-                tail_acc = fmaf(t4.w, tb4.w, tail_acc);
-            }
+            tail_acc = fmaf(t4.x, tb4.x, tail_acc);
+            tail_acc = fmaf(t4.y, tb4.y, tail_acc);
+            tail_acc = fmaf(t4.z, tb4.z, tail_acc);
+            tail_acc = fmaf(t4.w, tb4.w, tail_acc);
         }
-        if (B_KC) {
-            if (do_rowsum) rowsum_acc += (rs4.x + rs4.y) + (rs4.z + rs4.w);
-        }
+        if (B_KC) rowsum_acc += (rs4.x + rs4.y) + (rs4.z + rs4.w);
         __builtin_amdgcn_sched_barrier(0);
         GEMM_PROBE(6);
         wait_group0();

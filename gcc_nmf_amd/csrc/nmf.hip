@@ -132,12 +132,15 @@ unsigned* gccnmf_ticket_block(hipStream_t stream) {
 #endif
 
 extern "C" {
+#ifdef GCCNMF_EXPERIMENTS
 int gccnmf_debug_set_trace(long long* buf, int blocks) {
     GCCNMF_ENTER();
     gccnmf_trace_buf = buf;
     gccnmf_trace_blocks = buf ? blocks : 0;
     return GCCNMF_OK;
 }
+
+#endif
 
 int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
     GCCNMF_ENTER();
@@ -151,6 +154,7 @@ int gccnmf_pitches(int F, int T, int K, int* Fp, int* Kp, int* Np, int* Tp) {
 }
 }
 
+#ifdef GCCNMF_EXPERIMENTS
 // MFMA-only probe: what the f32 matrix pipe sustains on this box (clock included), nothing but 8 independent
 // accumulator chains per wave, two waves per SIMD.  grid = 512 blocks of 256 threads.
 __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(float* out, int iters) {
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(float* out, int iters
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 123.456f) out[0] = s;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // small K-vector kernels
@@ -1292,6 +1297,7 @@ int gccnmf_klnmf_shared_run(const gccnmf_shared_shard* shards, int nshards, floa
     return shared_finish(sh, nshards, hscale, K, s);
 }
 
+#ifdef GCCNMF_EXPERIMENTS
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
     GCCNMF_ENTER();
     if (!scratch || blocks < 1 || iters < 1) return GCCNMF_ERR_ARG;
@@ -1299,6 +1305,7 @@ int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream) 
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
+#endif
 
 int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items) {
     GCCNMF_ENTER();

@@ -260,15 +260,11 @@ int gccnmf_reconstruct(const float* W, const float* H, const unsigned char* argm
 int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int batch, const float* window,
                      const float* twiddle, float gain, int center, float* frames, float* y, void* stream);
 
-/* The overlap-add half of the call above on its own: frames [batch][nsig][T][n_fft] (windowed time frames, e.g. a neighbour
- * shard's last frames followed by this shard's own) -> y [batch][nsig][L] = samples first_sample .. first_sample+L-1 of the
- * overlap-added stream, frames added in ascending order (librosaSTFT.py:275-281), times gain.  Used by the time-sharded
+/* The overlap-add half of the call above on its own, for ONE file whose frame sequence is `halo` frames of `prev` [nsig][halo][n_fft]
+ * (the previous time shard's last frames; NULL with halo = 0: this file's frames alone) followed by the T frames of `frames`
+ * [nsig][T][n_fft] (windowed time frames) -- no concatenated copy of the two -> y [nsig][L] = samples first_sample .. first_sample+L-1
+ * of the overlap-added stream, frames added in ascending order (librosaSTFT.py:275-281), times gain.  Used by the time-sharded
  * single-mixture mode, where a shard's first samples need the previous shard's last n_fft/hop - 1 frames. */
-int gccnmf_ola_frames(const float* frames, int nsig, int n_fft, int hop, int T, int batch, int first_sample, int L, float gain,
-                      float* y, void* stream);
-
-/* The same for ONE file whose frame sequence is `halo` frames of `prev` [nsig][halo][n_fft] (the previous time shard's last frames; may be
- * NULL with halo = 0) followed by the T frames of `frames` [nsig][T][n_fft] -- no concatenated copy of the two. */
 int gccnmf_ola_frames_halo(const float* prev, int halo, const float* frames, int nsig, int n_fft, int hop, int T, int first_sample, int L,
                            float gain, float* y, void* stream);
 
@@ -320,6 +316,7 @@ int gccnmf_rt_process_block_ll(const float* block_in, float* block_out, float* i
                                int target_mode, int separation_enabled, int localization_enabled, int localization_window,
                                int frames_mode, int numHUpdates, int out_delay_blocks, void* stream);
 
+#ifdef GCCNMF_EXPERIMENTS      /* libgccnmf_hip_exp.so (make EXPERIMENTS=1): measurement tooling of the lab build */
 /* Debug: per-workgroup timeline of the LDS-DMA GEMM launches (device buffer of 8 x int64 per workgroup: s_memrealtime
  * [100 MHz] at entry (slots 0 and 1), after the main loop, after the epilogue; [4] = xcc_id<<16 | HW_ID[15:0]).
  * Recorded for launches of at most `blocks` workgroups while buf != NULL (scripts/kbench.py --trace). */
@@ -328,6 +325,7 @@ int gccnmf_debug_set_trace(long long* buf, int blocks);
 /* Diagnostics: a pure v_mfma_f32_32x32x2_f32 loop (blocks x 4 waves x iters x 8 instructions, 2*32*32*2 flop each):
  * the matrix-pipe rate this box sustains, quoted next to the roofline fractions. */
 int gccnmf_debug_mfma_peak(float* scratch, int blocks, int iters, void* stream);
+#endif
 
 /* Latency-path GEMM with the KL-NMF element-wise work fused (csrc/direct.hip): what gccnmf_klnmf runs for ONE mixture alone
  * (performKLNMF(V (513, 1244), 1024, 100, 0) is four of these + the W update per iteration), exported so that it can be tested

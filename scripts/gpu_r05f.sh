@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5: epilogue per column block (16 independent quotients, then 16 stores) + tuning snapshot + product/experiment split, vs round 4.
-TAG=${1:-r05f}
+TAG=${1:-r05g}
 OUT=gpurun_out/$TAG; export OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -28,8 +28,8 @@ b new_rcp GCCNMF_TUNE=7=0
 b r04_2 GCCNMF_HIP_LIB=$OLD
 b new_2 GCCNMF_TUNE=
 for f in 64; do
-  timeout 300 python scripts/ktrace.py --files $f --stage 3 --repeat 3 > $OUT/ktrace_new_f${f}.txt 2>&1; sed -n 2,5p $OUT/ktrace_new_f${f}.txt
-  GCCNMF_TUNE=7=0 timeout 300 python scripts/ktrace.py --files $f --stage 3 --repeat 3 > $OUT/ktrace_new_rcp_f${f}.txt 2>&1; sed -n 2,5p $OUT/ktrace_new_rcp_f${f}.txt
+  GCCNMF_HIP_LIB=$EXP timeout 300 python scripts/ktrace.py --files $f --stage 3 --repeat 3 > $OUT/ktrace_new_f${f}.txt 2>&1; sed -n 2,5p $OUT/ktrace_new_f${f}.txt
+  GCCNMF_HIP_LIB=$EXP GCCNMF_TUNE=7=0 timeout 300 python scripts/ktrace.py --files $f --stage 3 --repeat 3 > $OUT/ktrace_new_rcp_f${f}.txt 2>&1; sed -n 2,5p $OUT/ktrace_new_rcp_f${f}.txt
   GCCNMF_HIP_LIB=$OLD timeout 300 python scripts/ktrace.py --files $f --stage 3 --repeat 3 > $OUT/ktrace_r04_f${f}.txt 2>&1; sed -n 2,5p $OUT/ktrace_r04_f${f}.txt
 done
 FILES="32 51 80" bash scripts/files_sweep.sh > $OUT/files_sweep.txt 2>&1; cat $OUT/files_sweep.txt

@@ -72,9 +72,11 @@ def main():
         'K1 shape, no tail row (M=512)': lambda: dbg(W, H, G2, 512, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
         'K4a shape -> R buffer': lambda: dbg(V, H, R, F, K, N, g.Np, g.Np, g.Np, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Np),
     }
+    if not hasattr(lib, 'gccnmf_debug_mfma_peak'):          # the product library: no LDS-free stream tile (debug_gemm layout bit 32 is an experiment build's)
+        cases = {k: v for k, v in cases.items() if 'stream tile' not in k}
     # pure-MFMA probe: 512 blocks x 4 waves x 8 x 4096 MFMAs
     scratch = torch.zeros(16, device=dev)
-    for blocks in (256, 512, 1024):
+    for blocks in ((256, 512, 1024) if hasattr(lib, 'gccnmf_debug_mfma_peak') else ()):      # the probe lives in the experiment build
         lib.gccnmf_debug_mfma_peak(_ptr(scratch), blocks, 4096, _stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -21,6 +21,8 @@ def main():
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
+    if not hasattr(lib, 'gccnmf_debug_set_trace'):
+        sys.exit('needs the experiment build: make -C gcc_nmf_amd/csrc EXPERIMENTS=1; GCCNMF_HIP_LIB=gcc_nmf_amd/libgccnmf_hip_exp.so')
     F, T, K, B = 513, 622, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N

@@ -20,6 +20,8 @@ def main():
     from gcc_nmf_amd import _hip
     from gcc_nmf_amd.engine import Geometry, _ptr, _stream
     lib = _hip.lib()
+    if not hasattr(lib, 'gccnmf_debug_set_trace'):
+        sys.exit('needs the experiment build: make -C gcc_nmf_amd/csrc EXPERIMENTS=1; GCCNMF_HIP_LIB=gcc_nmf_amd/libgccnmf_hip_exp.so')
     for kv in filter(None, os.environ.get('TUNE', '').split(',')):       # e.g. TUNE=8=2,9=3
         key, val = [int(v) for v in kv.split('=')]
         assert lib.gccnmf_set_tuning(key, val) == 0, kv

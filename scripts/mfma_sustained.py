@@ -11,6 +11,8 @@ from gcc_nmf_amd import _hip                            # noqa: E402
 from gcc_nmf_amd.engine import _ptr, _stream            # noqa: E402
 
 lib = _hip.lib()
+if not hasattr(lib, 'gccnmf_debug_mfma_peak'):
+    sys.exit('needs the experiment build: make -C gcc_nmf_amd/csrc EXPERIMENTS=1; GCCNMF_HIP_LIB=gcc_nmf_amd/libgccnmf_hip_exp.so')
 scratch = torch.zeros(16, device='cuda')
 
 

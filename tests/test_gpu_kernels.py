@@ -99,6 +99,8 @@ def test_debug_gemm(hip, layout, M, N, Kd, batch):
     rc = lib.gccnmf_debug_gemm(dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), M, N, Kd, lda, ldb, ldc, a_clamp, b_clamp, layout,
                                batch, Ad[0].size, Bd[0].size, M * ldc, 0 if dscale is None else dscale.data_ptr(),
                                0 if drow is None else drow.data_ptr(), stream())
+    if (layout & 32) and rc == 3:
+        pytest.skip('the LDS-free stream tile (layout bit 32) exists in experiment builds only: make EXPERIMENTS=1')
     assert rc == 0
     torch.cuda.synchronize()
     C = dC.cpu().numpy()

@@ -13,20 +13,37 @@ from conftest import REPO, golden
 HEADER = os.path.join(REPO, 'include', 'gccnmf_hip.h')
 
 
-def declared_functions():
+def declared_functions(experiments=False):
+    """Entry points the header declares: for the product build, or (experiments=True) with the `#ifdef GCCNMF_EXPERIMENTS` blocks."""
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    if not experiments:
+        src = re.sub(r'#ifdef GCCNMF_EXPERIMENTS.*?#endif', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(?:int|long|gccnmf_allreduce_fn)\s+(gccnmf_\w+)\s*\(', src)))
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize('flavor', ['product', 'experiments'])
+def test_library_exports_every_declared_symbol(flavor):
+    """Header, ctypes table and shared object agree entry point by entry point -- for the product library, and for the lab build
+    (make EXPERIMENTS=1) with the header's GCCNMF_EXPERIMENTS blocks when that library has been built."""
     from gcc_nmf_amd import _hip
-    names = declared_functions()
-    assert len(names) >= 20
-    handle = ctypes.CDLL(_hip.LIB_PATH)
+    path = _hip.LIB_PATH if flavor == 'product' else os.path.join(os.path.dirname(_hip.LIB_PATH), 'libgccnmf_hip_exp.so')
+    if flavor == 'experiments' and not os.path.exists(path):
+        pytest.skip('libgccnmf_hip_exp.so has not been built (make -C gcc_nmf_amd/csrc EXPERIMENTS=1)')
+    names = declared_functions(experiments=(flavor == 'experiments'))
+    product = declared_functions()
+    assert 40 <= len(product) <= 43, 'the product header is meant to shrink, not grow'
+    handle = ctypes.CDLL(path)
     for n in names:
         assert hasattr(handle, n), n
-    assert sorted(_hip.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert sorted(_hip.SIGNATURES) == product, 'ctypes table and header disagree'
+    assert sorted(set(_hip.SIGNATURES) | set(_hip.EXPERIMENT_SIGNATURES)) == declared_functions(experiments=True)
+    if flavor == 'product':
+        for n in _hip.EXPERIMENT_SIGNATURES:
+            assert not hasattr(handle, n), 'the product library must not carry %s' % n
+        assert handle.gccnmf_set_tuning(18, 0) != 0 and handle.gccnmf_set_tuning(1, 0) != 0          # experiment keys are rejected
+    else:
+        assert handle.gccnmf_set_tuning(18, 0) == 0
     assert _hip.lib().gccnmf_version() >= 100
 
 
