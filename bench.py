@@ -524,7 +524,7 @@ def main():
         flop_per_launch = (2 if slabs else 1) * gemm_flop
         achieved = flop_per_launch / (k3_ms * 1e-3) / 1e12
         kernel_name = ('gccnmf_whdiv_rht_kernel (K3 + K4a in one launch: U = (V / (W.H)) . H^T, R never written)' if slabs else
-                       'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL> (K1/K3: W.H with V/(.) epilogue)')
+                       'gccnmf_gemm_dma_kernel<A_KC,!B_KC,EPI_DIV,TAIL,TM=4,NARROW> (K1/K3: W.H with V/(.) epilogue; 19 wide + 1 narrow item per file)')
         out['roofline'] = {'bound': 'mfma', 'kernel': kernel_name,
                            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
                            'traffic': None, 'flop_per_launch': flop_per_launch, 'avg_launch_ms': float(k3_ms),

@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--K', type=int, default=1024)
     ap.add_argument('--stage', type=int, default=1)
     ap.add_argument('--dump', default='')
+    ap.add_argument('--resident', action='store_true', help='experiment build: 512 resident workgroups pulling tiles by ticket (tuning key 18); with --probe the per-phase cycles are per RESIDENT workgroup, summed over its tiles')
+    ap.add_argument('--no-prefetch', action='store_true', help='with --resident: tuning key 19 = 0')
     ap.add_argument('--repeat', type=int, default=0, help='launch the stage this many times right before the traced launch (back-to-back launches of one kernel)')
     ap.add_argument('--probe', action='store_true', help='library built with -DGEMM_DMA_PROBE: per-phase cycles of the k-tile')
     a = ap.parse_args()
@@ -29,6 +31,8 @@ def main():
     lib = _hip.lib()
     if not hasattr(lib, 'gccnmf_debug_set_trace'):
         sys.exit('needs the experiment build: make -C gcc_nmf_amd/csrc EXPERIMENTS=1; GCCNMF_HIP_LIB=gcc_nmf_amd/libgccnmf_hip_exp.so')
+    if a.resident:
+        assert lib.gccnmf_set_tuning(18, 1) == 0 and lib.gccnmf_set_tuning(19, 0 if a.no_prefetch else 1) == 0, 'needs the experiment build'
     F, T, K, B = 513, 622, a.K, a.files
     g = Geometry(F, T, K)
     N = g.N
@@ -60,7 +64,25 @@ def main():
     tiles = {1: 1 * (g.Np // 64), 3: 1 * (g.Np // 64), 2: -(-K // 512) * (g.Np // 64), 4: -(-K // 64)}[a.stage]
     grid = 8 * (-(-B // 8)) * tiles
     t = t_all[:max(grid, int(np.nonzero(t_all[:, 0])[0].max()) + 1)] if not a.probe else t_all[:grid]
-    if a.probe:
+    if a.probe and a.resident:
+        # the resident grid: rows [classic grid + 4 * workgroup + wave] = cycles per phase summed over ALL tiles of that workgroup, [7] = its tiles
+        import ctypes
+        plan = (ctypes.c_int * 8)()
+        Mo, No = {1: (512, N), 3: (512, N), 2: (K, N), 4: (512, K)}[a.stage]
+        lib.gccnmf_debug_gemm_plan(Mo, No, B, 1, 0, 1 if a.stage != 4 else 0, plan, None, 0)
+        cg = plan[7]
+        pr = t_all[cg:cg + 4 * 512].reshape(512, 4, 8).astype(np.float64)
+        items = pr[:, 0, 7]
+        nkt = {1: K // 16, 3: K // 16, 2: (F - 1) // 16, 4: g.Np // 16}[a.stage]
+        names = ['G1 issue + 32 MFMA + DMA', 'wait G1', '8 MFMA', 'wait DMA, arrive, 16 MFMA', 'split-barrier wait', 'G0 issue + 8 MFMA', 'wait G0']
+        print('resident grid, stage %d, %d files: classic grid %d items on 512 workgroups; tiles per workgroup min %d median %d max %d' % (
+            a.stage, B, cg, items.min(), np.median(items), items.max()))
+        per = pr[:, :, :7] / np.maximum(items, 1)[:, None, None] / nkt          # cycles per k-tile (wide-tile equivalents are not separated from narrow ones)
+        m = per.mean(axis=(0, 1))
+        print('  cycles per k-tile, mean over workgroups and waves: %.0f (solo MFMA time of a wide tile: 4096)' % m.sum())
+        for n, v, w in zip(names, m, per.mean(axis=0).T):
+            print('     %-28s %7.0f   per wave: %s' % (n, v, '  '.join('%6.0f' % x for x in w)))
+    elif a.probe:
         pr = t_all[grid:5 * grid, :7].reshape(grid, 4, 7).astype(np.float64)
         nkt = {1: K // 16, 3: K // 16, 2: (F - 1) // 16, 4: g.Np // 16}[a.stage]
         names = ['G1 issue + 32 MFMA + DMA', 'wait G1', '8 MFMA', 'wait DMA, arrive, 16 MFMA', 'split-barrier wait', 'G0 issue + 8 MFMA', 'wait G0']
