@@ -316,6 +316,8 @@ def config_lines(a, e, xs, sr, n, local_rank):
     e.iters = 200
     dt = timed_runs(e, 2)
     e.iters = a.iterations
+    e.run()                              # e.y is the headline configuration's result again (the CPU-baseline leg compares it with the oracle)
+    torch.cuda.synchronize()
     res['it200'] = {'files': B, 'nmf_iterations': 200, 'frames_per_s': B * e.g.T / dt, 'ms_per_step': 1e3 * dt, 'what': 'BASELINE config 3 as written'}
     # config 4's per-rank shape: one dictionary for the rank's files (no exchange at one rank)
     from gcc_nmf_amd.distributed import HipSharedNMF, shared_initial_factors, train_shared_dictionary
