@@ -404,48 +404,54 @@ __device__ __forceinline__ void gemm_epilogue_update_w_full(const GemmArgs& p, i
 
 // ---- the work list of a launch ---------------------------------------------------------------------------------------------
 // A launch is an ORDERED list of work items per XCD (GemmArgs.lists = 8: XCD x = blockIdx & 7 serves list x; 1: one list), taken in
-// order by the hardware dispatcher (workgroup b takes item b >> 3 of list b & 7; the experiment build can also hand them out to
-// resident workgroups through a ticket counter).  An item is one output tile, computed by ONE workgroup in the fixed k order, so a
-// file's bits depend neither on who takes an item nor on the form it has.  List x is the contiguous chunk [x * cw, (x + 1) * cw) of
-// the file-major tile list (files in the class order 0, 8, 16, ... | 1, 9, ... so that a file's tiles share one XCD's L2); an item is
-//   wide    512 x 64   a full tile
-//   ragged  512 x 32   the last column tile of a file when at most 32 of its 64 columns exist (N = 1244 = 19 x 64 + 28; rag = 1): a
-//                      NARROW item in the tile's natural place -- half the matrix work of the padded tile it replaces
-//   halves  512 x 32   the last `split` tiles of a list as two narrow items each, left / right 32 columns (tests: every tile)
+// order -- by the hardware dispatcher (classic grid: workgroup b takes item b >> 3 of list b & 7) or by resident workgroups through
+// a ticket counter (persistent grid, below).  An item is one output tile, computed by ONE workgroup in the fixed k order, so a
+// file's bits depend neither on who takes an item nor on the form it has.  Three kinds, longest first:
+//   wide    512 x 64   items 0 .. len - split - 1 of a list: its chunk [list * cw, ...) of the file-major list of wide tiles
+//                      (files in the class order 0, 8, 16, ... | 1, 9, ... so that a file's tiles share one XCD's L2)
+//   halves  512 x 32   the last `split` wide tiles of the chunk as two NARROW items each (left / right 32 columns): finer grain for
+//                      the end of a launch that would otherwise leave CUs idle (host-side list-scheduling model, gemm_dma_plan)
+//   ragged  512 x 32   the last column tile of a file when at most 32 of its 64 columns exist (N = 1244 = 19 x 64 + 28): half the
+//                      matrix work of the padded tile it replaces (rag = 1; chunk [list * cr, ...) of the file-major list)
 // A narrow item runs the same loop without the MFMAs of the right column block: same k order per element -> same bits.
-// Returns 0 = the list has ended, 1 = an item, 2 = an item without columns (the right half of a ragged tile): nothing to do.
 __host__ __device__ __forceinline__ int gemm_dma_list_file(const GemmArgs& p, int q) {      // position q in the class order -> file
     if (p.lists != 8) return q;
     const int n_full = p.batch >> 3, rem = p.batch & 7, big = rem * (n_full + 1);
     const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
     return cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
 }
-__host__ __device__ __forceinline__ int gemm_dma_item(const GemmArgs& p, int list, int t, int& file, int& tm, int& col0, int& nw) {
-    const int wt = p.tiles_m * p.tiles_n;                     // tiles per file
-    const int base = list * p.cw;
-    const int len = min(max(p.batch * wt - base, 0), p.cw), s = min(p.split, len);
-    if (t >= len + s) return 0;
-    int idx, half = -1;
-    if (t < len - s) {
-        idx = base + t;
+__host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int list, int t, int& file, int& tm, int& col0, int& nw) {
+    const int wt = p.tiles_m * p.wide_n;                      // wide tiles per file
+    const int base_w = list * p.cw;
+    const int len = min(max(p.batch * wt - base_w, 0), p.cw), s = min(p.split, len);
+    int q;
+    if (t < len + s) {
+        int idx, half = 0;
+        if (t < len - s) {
+            idx = base_w + t;
+            nw = 2;
+        } else {
+            const int j = t - (len - s);
+            idx = base_w + (len - s) + (j >> 1);
+            half = j & 1;
+            nw = 1;
+        }
+        q = idx / wt;
+        const int w = idx - q * wt;
+        tm = w / p.wide_n;
+        col0 = (w - tm * p.wide_n) * 64 + 32 * half;
     } else {
-        const int j = t - (len - s);
-        idx = base + (len - s) + (j >> 1);
-        half = j & 1;
+        const int r = t - (len + s), base_r = list * p.cr;
+        const int lenr = min(max(p.batch * p.rag * p.tiles_m - base_r, 0), p.cr);
+        if (r >= lenr) return false;
+        const int idx = base_r + r;
+        q = idx / p.tiles_m;
+        tm = idx - q * p.tiles_m;
+        col0 = (p.tiles_n - 1) * 64;
+        nw = 1;
     }
-    const int q = idx / wt, w = idx - q * wt;
-    tm = w / p.tiles_n;
-    const int tn = w - tm * p.tiles_n;
-    const bool ragged = p.rag && tn == p.tiles_n - 1;
     file = gemm_dma_list_file(p, q) + p.file0;
-    if (half < 0) {
-        nw = ragged ? 1 : 2;
-        col0 = tn * 64;
-        return 1;
-    }
-    nw = 1;
-    col0 = tn * 64 + 32 * half;
-    return (ragged && half == 1) ? 2 : 1;
+    return true;
 }
 
 // The throughput tile: 512 x 64 per workgroup, 128 x 64 per wave (TM = 4 MFMA row tiles x 2 column blocks).
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
     __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * BM : 4];   // lean epilogue row factors
     __shared__ unsigned s_arrivals;                  // split barrier of the main loop: 4 arrivals per k-tile
-    __shared__ int s_ticket[3];                      // persistent grid: the next item of this workgroup (alternating slots 0 / 1; 2 = synchronous re-fetch)
+    __shared__ int s_ticket[2];                      // persistent grid: the next item of this workgroup (alternating slots)
 
     // Per-lane values are RE-DERIVED per item from an opaque copy of the thread index (gemm_opaque_tid): as loop invariants of the item
     // loop they would stay live across the epilogue, whose 128 accumulators + two tile pairs of inputs leave no registers for them.
@@ -493,10 +499,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     unsigned long long tail_mask = 0, scale_mask = 0;                 // lane masks of wave 0's side-chunk pieces (0 = no-op)
     bool wave_active = false, do_tail = false, do_rowsum = false;
     unsigned offA[NA], offB = 0;                                       // per-lane source offsets (bytes from the wave-uniform k-tile origin) of this wave's DMA pieces
-    auto take_item = [&](const int ticket) -> int {                    // 0 = the list has ended, 1 = item set up, 2 = an item without columns
+    auto take_item = [&](const int ticket) -> bool {
         int f_, tm_, c_, nw_;
-        const int status = gemm_dma_item(p, list, ticket, f_, tm_, c_, nw_);
-        if (status != 1) return status;
+        if (!gemm_dma_item(p, list, ticket, f_, tm_, c_, nw_)) return false;
         // (the integer divisions of the decode run on the VALU: without the readfirstlanes every value derived from file / tile -- all
         // row pointers, descriptors and scalar offsets below -- stays in VGPRs and each buffer access becomes a waterfall loop)
         file = __builtin_amdgcn_readfirstlane(f_);
@@ -514,22 +519,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         tail_mask = (wave == 0 && do_tail) ? 0x0full : 0ull;
         scale_mask = (wave == 0 && bscale != nullptr) ? 0xf0ull : 0ull;
         scale_src = bscale != nullptr ? bscale : A;              // (never dereferenced under a zero mask; kept a valid address anyway)
-        return 1;
+        return true;
     };
-#ifdef GCCNMF_EXPERIMENTS
-    // resident grid: the next item that has work, taking further tickets synchronously past items without columns (rare: the right
-    // half of a ragged tile in the all-halves test form)
-    auto take_nonempty = [&](int& ticket, int status) -> bool {
-        while (status == 2) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_ticket[2] = p.wpl + (int)__hip_atomic_fetch_add(p.tickets + list, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            ticket = __builtin_amdgcn_readfirstlane(s_ticket[2]);
-            status = take_item(ticket);
-        }
-        return status == 1;
-    };
-#endif
     auto set_offsets = [&](const int lane) {                           // this wave's DMA source offsets for the current item
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -825,11 +816,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     if (SCALE) {
         if (!p.bscale && tid < 2 * BK) smem[(tid >> 4) * SBUF + SA + SB + BK + (tid & 15)] = 1.f;       // no row scale: both chunks stay 1
     }
-#ifdef GCCNMF_EXPERIMENTS
-    bool have = persistent ? take_nonempty(t, take_item(t)) : take_item(t) == 1;
-#else
-    bool have = take_item(t) == 1;
-#endif
+    bool have = take_item(t);
     if (have) set_offsets(lane);
     bool prefetched = false;                           // the first k-tile of the current item is already on its way into buffer 0
     int it = 0;                                        // items done by this workgroup (ticket slot = it & 1)
@@ -904,9 +891,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
         prefetched = false;
         if (persistent) {
             t = __builtin_amdgcn_readfirstlane(s_ticket[it & 1]);
-#ifdef GCCNMF_EXPERIMENTS
-            have = take_nonempty(t, take_item(t));
-#endif
+            have = take_item(t);
             if (have && p.prefetch) {
                 set_offsets(gemm_opaque_tid() & 63);           // (computed again at the top of the next item: not kept across the epilogue)
 #pragma unroll
@@ -1009,9 +994,10 @@ unsigned* gccnmf_ticket_block(hipStream_t stream);
 
 // The work lists of one launch of TM-high tiles over the files [a.file0, a.file0 + a.batch).  narrow_capable: the kernel instantiation
 // carries the 512 x 32 loop.  Returns the size of the classic grid (items of the longest list x lists), -1 on overflow.
-//   key 9 = 0: wide tiles only | 1 (default): a file's ragged last column tile (at most 32 of its 64 columns exist) is a narrow item, in
-//   its natural place in the list (the same number of items as with padded tiles: never a round of workgroup slots more; the file's W
-//   panel is still in the XCD's L2 when its ragged tile runs) | 2 (tests): every tile as two narrow halves
+//   key 9 = 0: wide tiles only | 1 (default): a file's ragged last column tile (at most 32 of its 64 columns exist) becomes a narrow item
+//   when the launch shares the chip with another file group's launches (its early finish is used at once), or when the extra items do not
+//   cost the launch another round of workgroup slots (51 files: 128 tiles per XCD fit two rounds of 64, 122 + 7 items do not) | 2 (tests):
+//   every tile as two narrow halves
 static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM) {
     a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
@@ -1021,9 +1007,18 @@ static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM) {
     const long tiles = (long)a.batch * a.tiles_m * a.tiles_n;
     if (tiles > (1L << 28)) return -1;
     a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;
-    a.cw = (int)((tiles + a.lists - 1) / a.lists);
+    if (a.rag && policy == 1 && !a.concurrent) {
+        const long slots = a.lists == 8 ? 64 : 512;
+        const long plain = (tiles + a.lists - 1) / a.lists;
+        const long with_rag = ((long)a.batch * a.tiles_m * (a.tiles_n - 1) + a.lists - 1) / a.lists + ((long)a.batch * a.tiles_m + a.lists - 1) / a.lists;
+        if ((with_rag + slots - 1) / slots > (plain + slots - 1) / slots) a.rag = 0;
+    }
+    a.wide_n = a.tiles_n - a.rag;
+    const long wide = (long)a.batch * a.tiles_m * a.wide_n, ragged = (long)a.batch * a.rag * a.tiles_m;
+    a.cw = (int)((wide + a.lists - 1) / a.lists);
+    a.cr = (int)((ragged + a.lists - 1) / a.lists);
     a.split = (narrow_ok && policy == 2) ? a.cw : 0;
-    return a.lists * (a.cw + a.split);
+    return a.lists * (a.cw + a.split + a.cr);
 }
 
 // One launch of TM-high tiles over the files [a.file0, a.file0 + a.batch)

@@ -92,9 +92,9 @@ struct GemmArgs {
     long long* trace;          // debug: per-workgroup timeline, 8 x int64 per block (gccnmf_debug_set_trace)
     // LDS-DMA throughput tile (gemm_dma.h): the launch's work lists, set by gccnmf_launch_gemm_dma
     int lists;                 // 8 = one ordered item list per XCD (blockIdx & 7), 1 = one list
-    int cw;                    // tiles per list: list x is the chunk [x * cw, (x + 1) * cw) of the file-major tile list
-    int split;                 // the last `split` tiles of every list run as two narrow (512 x 32) halves (tests: all of them)
-    int rag;                   // 1: the last column tile of a file has at most 32 columns and is a narrow item
+    int cw, cr;                // wide tiles / ragged narrow tiles per list (chunks of the file-major lists)
+    int split;                 // the last `split` wide tiles of every list run as two narrow (512 x 32) halves
+    int rag, wide_n;           // rag = 1: the last column tile of a file is a narrow item; wide_n = tiles_n - rag
     int wpl, prefetch;         // persistent grid: resident workgroups per list; 1 = the next item's first k-tile is requested before the epilogue
     unsigned* tickets;         // persistent grid: [0..7] next-item counters per list, [8] workgroups gone; nullptr = classic grid
     int trace_rows, trace_grid;   // rows of the trace buffer; items of the classic grid (the per-wave probe rows start behind them)

@@ -1314,15 +1314,13 @@ int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurre
     a.M = M; a.N = N; a.batch = batch; a.xcd_affine = xcd_affine; a.concurrent = concurrent;
     const int grid = gemm_dma_plan(a, narrow_capable != 0, 4);
     if (grid < 1) return -1;
-    const int fields[8] = {a.lists, a.cw, 0, a.split, a.rag, a.tiles_m, a.tiles_n, grid};
+    const int fields[8] = {a.lists, a.cw, a.cr, a.split, a.rag, a.tiles_m, a.tiles_n, grid};
     for (int i = 0; i < 8; ++i) plan[i] = fields[i];
     int n = 0;
     for (int list = 0; list < a.lists; ++list)
         for (int t = 0;; ++t) {
             int file, tm, col0, nw;
-            const int status = gemm_dma_item(a, list, t, file, tm, col0, nw);      // the same decode the kernel runs
-            if (status == 0) break;
-            if (status == 2) continue;                                             // an item without columns: its workgroup exits at once
+            if (!gemm_dma_item(a, list, t, file, tm, col0, nw)) break;      // the same decode the kernel runs
             if (n < max_items) {
                 int* it = items + 6 * n;
                 it[0] = list; it[1] = t; it[2] = file; it[3] = tm; it[4] = col0; it[5] = nw;

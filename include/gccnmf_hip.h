@@ -60,8 +60,8 @@ int gccnmf_version(void);
  * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
  * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout; outputs
  * of at most 256 rows always take half-height tiles; a file's ragged last column tile (at most 32 of its 64 columns exist: N = 1244)
- * is a NARROW (512 x 32) item: half the matrix work of the padded tile.  Same k order per element: bitwise the same results in every
- * form.  0 = full tiles only; 2 = every full tile as two narrow halves (tests).
+ * becomes a NARROW (512 x 32) item at the end of its XCD's list when that does not cost the launch another round of workgroup slots.
+ * Same k order per element: bitwise the same results in every form.  0 = full tiles only; 2 = every full tile as two narrow halves (tests).
  * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..8, default 4).
@@ -379,7 +379,7 @@ int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, v
 
 /* Diagnostics (tests only, no device needed): the work lists a throughput-tile launch (csrc/gemm_dma.h) would use for an M x N output
  * over `batch` files under the current tuning -- the SAME tile decode the kernel runs, executed on the host.
- *   plan  [8]: lists, tiles per list, 0, split, rag, tiles_m, tiles_n, workgroups of the classic grid
+ *   plan  [8]: lists, wide tiles per list, ragged narrow tiles per list, split, rag, tiles_m, tiles_n, items of the classic grid
  *   items [max_items][6]: list, ticket, file, row tile, first column, column blocks (2 = 512 x 64, 1 = a narrow 512 x 32 item)
  * Returns the number of items (all lists), -1 on bad arguments. */
 int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items);

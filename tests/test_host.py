@@ -112,9 +112,9 @@ def _gemm_plan(lib, M, N, batch, xcd=1, concurrent=0, narrow=1):
 
 def test_throughput_tile_work_lists_cover_every_tile_exactly_once():
     """The ordered item lists of a throughput-tile launch (csrc/gemm_dma.h; gccnmf_debug_gemm_plan runs the kernel's own tile decode on
-    the host): in every form -- wide tiles only, ragged narrow tiles, every tile as two narrow halves -- each 32-column block of every
-    (file, row tile) is computed by exactly one item, a list's tickets are dense, and a ragged last column tile (N = 1244 = 19 x 64 + 28)
-    costs one narrow item, in the tile's own place, instead of a padded wide one."""
+    the host): in every form -- wide tiles only, narrow ragged tiles, everything split -- each 32-column block of every (file, row tile)
+    is computed by exactly one item, items of a list are ordered longest first, and a ragged last column tile (N = 1244 = 19 x 64 + 28)
+    costs one narrow item instead of a padded wide one where that does not cost the launch another round of workgroup slots."""
     from gcc_nmf_amd import _hip
     lib = _hip.lib()
     try:
@@ -133,21 +133,22 @@ def test_throughput_tile_work_lists_cover_every_tile_exactly_once():
                         need[:, :, -1] = 0                       # columns that do not exist: nobody computes them
                         assert policy != 0 and N - 64 * (pl['tiles_n'] - 1) <= 32
                     assert np.array_equal(cover, need), (policy, M, N, B)
-                    for lst in range(pl['lists']):               # ascending tickets (an item without columns leaves a gap in the all-halves form)
+                    for lst in range(pl['lists']):               # longest first: wide, then narrow; tickets are dense
                         mine = items[items[:, 0] == lst]
-                        assert np.all(np.diff(mine[:, 1]) >= 1) and (policy == 2 or np.array_equal(mine[:, 1], np.arange(len(mine))))
+                        assert np.array_equal(mine[:, 1], np.arange(len(mine))) and np.all(np.diff(mine[:, 5]) <= 0)
                     if policy == 0:
                         assert pl['rag'] == 0 and pl['split'] == 0 and np.all(items[:, 5] == 2)
                     if policy == 2:
                         assert np.all(items[:, 5] == 1)
                     if policy == 1:
-                        assert pl['split'] == 0 and pl['grid'] == pl['lists'] * pl['cw']        # never a workgroup more than with padded tiles
+                        assert pl['split'] == 0
         assert lib.gccnmf_set_tuning(9, 1) == 0
-        # the headline shape: 19 wide + 1 narrow item per file, the narrow one where the padded tile was (its file's W panel is still in L2)
+        # the headline shape: 19 wide + 1 narrow item per file instead of 20 wide ones (152 + 8 = the 160 slots per XCD the padded tiles take)
         pl, items = _gemm_plan(lib, 512, 1244, 64)
-        assert (pl['cw'], pl['split'], pl['rag']) == (160, 0, 1) and (items[:, 5] == 1).sum() == 64
-        first = items[items[:, 0] == 0][:20]
-        assert np.all(first[:, 2] == first[0, 2]) and first[:19, 5].tolist() == [2] * 19 and first[19, 5] == 1 and first[19, 4] == 19 * 64
+        assert (pl['cw'], pl['cr'], pl['split'], pl['rag']) == (152, 8, 0, 1) and (items[:, 5] == 1).sum() == 64
+        # 51 files: 128 padded tiles per XCD are exactly two rounds of 64 slots, 122 + 7 items would start a third -> wide tiles, unless the
+        # launch shares the chip with another file group's (its early finishers are used at once)
+        assert _gemm_plan(lib, 512, 1244, 51)[0]['rag'] == 0 and _gemm_plan(lib, 512, 1244, 51, concurrent=1)[0]['rag'] == 1
         # a kernel instantiation without the narrow loop never gets narrow items
         pl, items = _gemm_plan(lib, 512, 1244, 26, narrow=0)
         assert pl['rag'] == 0 and pl['split'] == 0 and np.all(items[:, 5] == 2) and len(items) == 520
