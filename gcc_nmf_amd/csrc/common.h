@@ -46,7 +46,7 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //    3   dma               1     0..1    1 = throughput tiles stage operands by LDS-DMA (gemm_dma.h), 0 = through registers (gemm_mfma.h)
 //    7   exact_div         1     0..1    1 = V / (W.H) is the IEEE quotient, 0 = v_rcp_f32 + one Newton step
 //    8   shared_groups     3     1..4    file groups of a shared-dictionary shard that cannot fill the chip, on library-owned streams
-//    9   tail_split        1     0..2    throughput-tile launch forms: 1 = by the launcher's rules, 0 = full tiles only, 2 = all narrow halves (tests)
+//    9   tail_split        1     0..3    throughput-tile launch forms: 1 = by the launcher's rules, 0 = full tiles only, 2 = all narrow halves, 3 = all half-height (tests)
 //   10   direct            1     0..1    1 = launches that cannot fill the chip take the direct-to-register kernels (direct.hip)
 //   12   direct_batch      4     1..8    largest batch on the direct path
 //   16   fused_k12         1     0..2    K <= 128: K1 + K2 as one launch of column tiles (0 never, 1 by cost model, 2 always)

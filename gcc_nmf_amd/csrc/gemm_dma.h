@@ -1069,7 +1069,7 @@ static int gccnmf_launch_gemm_dma(GemmArgs a, hipStream_t stream) {
     a.ablate = gccnmf_tune_ablate;
     a.exact_div = gccnmf_tune_exact_div;
     if constexpr (EPI != EPI_UPDW) {
-        if (a.M <= 256 && gccnmf_tune_tail_split != 0) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
+        if ((a.M <= 256 && gccnmf_tune_tail_split != 0) || gccnmf_tune_tail_split == 3) return gccnmf_launch_gemm_dma_tm<A_KC, B_KC, EPI, TAIL, 2>(a, stream);
         const long tpf = (long)gccnmf_ceil_div(a.M, 512) * gccnmf_ceil_div(a.N, 64);     // throughput tiles per file
         const long total = tpf * a.batch, rounds = total / 512;
         // Decided by a cost model in units of one paired round of full tiles = 250 (measured at Kd = 1024: 0.25 ms; everything scales

@@ -37,7 +37,7 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {4, 1, 4, 1},                       //  6 rht_splits
     {1, 0, 1, 0},                       //  7 exact_div: the IEEE quotient since round 5 (measured cost on K1 / K3: 0.0 %, profiles/r05b_kbench_exact_div.txt)
     {3, 1, GCCNMF_SHARED_STREAMS, 0},   //  8 shared_groups
-    {1, 0, 2, 0},                       //  9 tail_split
+    {1, 0, 3, 0},                       //  9 tail_split (3 = half-height tiles everywhere: tests / measurements)
     {1, 0, 1, 0},                       // 10 direct
     {0, 0, 8, 1},                       // 11 direct_tile
     {4, 1, GCCNMF_DIRECT_MAX_BATCH, 0}, // 12 direct_batch (measured, K = 1024: 4 files 21.8 ms against 25.8 on the ring kernel, 8 files 41.5 / 41.3)

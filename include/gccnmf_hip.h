@@ -61,7 +61,7 @@ int gccnmf_version(void);
  * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout; outputs
  * of at most 256 rows always take half-height tiles; a file's ragged last column tile (at most 32 of its 64 columns exist: N = 1244)
  * becomes a NARROW (512 x 32) item at the end of its XCD's list when that does not cost the launch another round of workgroup slots.
- * Same k order per element: bitwise the same results in every form.  0 = full tiles only; 2 = every full tile as two narrow halves (tests).
+ * Same k order per element: bitwise the same results in every form.  0 = full tiles only; 2 = every full tile as two narrow halves, 3 = half-height tiles everywhere (tests / measurements).
  * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
  * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
  * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..8, default 4).

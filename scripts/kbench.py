@@ -44,7 +44,7 @@ def main():
     H[:, :K, :N] = torch.rand((B, K, N), device=dev, generator=gen) + 0.01
     ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), device=dev)
     U = torch.zeros((B, g.Fp, g.Kp), device=dev)
-    G2 = torch.zeros((B, g.Kp, g.Np), device=dev)
+    G2 = torch.zeros((B, max(g.Kp, g.Fp), g.Np), device=dev)          # also the target of F-row outputs (the 'other output buffer' cases)
     R = ws[:B * g.Fp * g.Np].view(B, g.Fp, g.Np)
 
     def stage(s):
@@ -67,9 +67,9 @@ def main():
         'K4a shape, store only (KC,KC, tail)': lambda: dbg(R, H, U, F, K, N, g.Np, g.Np, g.Kp, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Kp),
         'K1 shape, store only, ONE H for all files (B L2-resident)': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, 0, g.Fp * g.Np),
         'K1 shape, store only, ONE W,H, one output tile set': lambda: dbg(W, H, R, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, 0, 0, 0),
-        'K1 shape -> other output buffer': lambda: dbg(W, H, G2, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
-        'K1 shape, N=1280 (full last tile)': lambda: dbg(W, H, G2, F, g.Np, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
-        'K1 shape, no tail row (M=512)': lambda: dbg(W, H, G2, 512, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1, g.Fp * g.Kp, g.Kp * g.Np, g.Kp * g.Np),
+        'K1 shape -> other output buffer': lambda: dbg(W, H, G2, F, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, max(g.Kp, g.Fp) * g.Np),
+        'K1 shape, N=1280 (full last tile)': lambda: dbg(W, H, G2, F, g.Np, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1 | 4, g.Fp * g.Kp, g.Kp * g.Np, max(g.Kp, g.Fp) * g.Np),
+        'K1 shape, no tail row (M=512)': lambda: dbg(W, H, G2, 512, N, K, g.Kp, g.Np, g.Np, g.Fp - 1, g.Np - 4, 1, g.Fp * g.Kp, g.Kp * g.Np, max(g.Kp, g.Fp) * g.Np),
         'K4a shape -> R buffer': lambda: dbg(V, H, R, F, K, N, g.Np, g.Np, g.Np, g.Fp - 1, g.Kp - 1, 3 | 4, g.Fp * g.Np, g.Kp * g.Np, g.Fp * g.Np),
     }
     if not hasattr(lib, 'gccnmf_debug_mfma_peak'):          # the product library: no LDS-free stream tile (debug_gemm layout bit 32 is an experiment build's)

@@ -593,13 +593,14 @@ def test_narrow_items_and_resident_workgroups_are_bitwise(hip, F, T, K, B, flags
     W0, H0 = klnmf_initial_factors(F, N, K)
     dV = padded(V, (B, g.Fp, g.Np), 'cuda')
     outs = []
-    forms = [(0, 0, 0), (1, 0, 0), (2, 0, 0)]
-    if lib.gccnmf_set_tuning(18, 0) == 0:              # an experiment build (make EXPERIMENTS=1) also carries the resident-workgroup grid
+    forms = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0)]          # (3: half-height tiles everywhere)
+    experiments = lib.gccnmf_set_tuning(18, 0) == 0    # an experiment build (make EXPERIMENTS=1) also carries the resident-workgroup grid
+    if experiments:
         forms += [(0, 1, 0), (1, 1, 1), (2, 1, 1), (1, 1, 0)]
     try:
         for narrow, resident, prefetch in forms:
             assert lib.gccnmf_set_tuning(9, narrow) == 0
-            if len(forms) > 3:
+            if experiments:
                 assert lib.gccnmf_set_tuning(18, resident) == 0 and lib.gccnmf_set_tuning(19, prefetch) == 0
             assert lib.gccnmf_set_tuning(16, 0) == 0 and lib.gccnmf_set_tuning(17, 0) == 0          # K <= 128: the four-launch form, on the throughput tile
             dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')

@@ -92,7 +92,7 @@ def test_shared_run_argument_checks_and_workspace_sizes():
     assert lib.gccnmf_klnmf_shared_run(arr, 1, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1     # null shard pointers
     assert lib.gccnmf_klnmf_shared_run(None, 9, 8, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # > GCCNMF_MAX_SHARDS
     assert lib.gccnmf_klnmf_shared_run(None, 0, 0, 8, 8, 513, 1024, 1, 0.0, 1e-16, None, None, None) == 1    # no W
-    assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 3) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
+    assert lib.gccnmf_set_tuning(8, 5) == 1 and lib.gccnmf_set_tuning(9, 4) == 1 and lib.gccnmf_set_tuning(7, 3) == 1
     assert lib.gccnmf_set_tuning(18, 2) == 1 and lib.gccnmf_set_tuning(19, 2) == 1
     assert lib.gccnmf_set_tuning(10, 2) == 1 and lib.gccnmf_set_tuning(11, 9) == 1 and lib.gccnmf_set_tuning(12, 17) == 1
     assert lib.gccnmf_set_tuning(16, 3) == 1 and lib.gccnmf_set_tuning(17, 3) == 1 and lib.gccnmf_set_tuning(17, 1) == 0 and lib.gccnmf_set_tuning(16, 1) == 0
