@@ -46,18 +46,8 @@ __device__ __forceinline__ void gemm_dma16(const float* wave_uniform_base, unsig
                  : "memory");
 }
 
-// A piece fetched by a few lanes only (`mask`, compile-time): exec is narrowed and restored inside the asm, so the main loop
-// carries no v_cmp / s_and_saveexec for it.
-template <unsigned MASK>
-__device__ __forceinline__ void gemm_dma16_lanes(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr) {
-    unsigned long long saved;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved)
-                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_wave_byte_addr), "n"(MASK)
-                 : "memory");
-}
-
-// The same with a RUN-TIME wave-uniform lane mask (an SGPR pair): a mask of 0 makes the piece a no-op without a branch around it -- the
+// A piece fetched by a few lanes only: exec is narrowed to a RUN-TIME wave-uniform lane mask (an SGPR pair) and restored inside the asm, so
+// the main loop carries no v_cmp / s_and_saveexec for it, and a mask of 0 makes the piece a no-op without a branch around it -- the
 // side chunks of a k-tile (tail row of A, row scale of B) belong to wave 0 only, and a taken scalar branch per k-tile in the other
 // three waves is dearer than five scalar instructions in all four.
 __device__ __forceinline__ void gemm_dma16_masked(const float* wave_uniform_base, unsigned lane_byte_offset, unsigned lds_wave_byte_addr,

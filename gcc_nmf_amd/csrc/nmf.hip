@@ -75,9 +75,8 @@ long long* gccnmf_trace_buf = nullptr;
 int gccnmf_trace_blocks = 0;
 
 extern "C" {
-int gccnmf_version(void) {
-    GCCNMF_ENTER(); return 105; }   // round 4: direct latency GEMMs (gccnmf_gemm_direct), streaming at any even window, register-pass FFT,
-                                           // fused short-dictionary launches (tuning keys 16 / 17, gccnmf_klnmf_plan, GCCNMF_FLAG_GROUPS)
+int gccnmf_version(void) { return 106; }   // round 5: work lists with narrow items in the throughput tile (gccnmf_debug_gemm_plan), IEEE division by default,
+                                           // tuning keys as atomics snapshotted per call, product / experiment build flavours (42 product entry points)
 
 int gccnmf_set_tuning(int key, int value) {
     GCCNMF_ENTER();
