@@ -61,7 +61,8 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //   15 X fft_r16           1     0..1    0 = one radix-2 stage per LDS round trip in the offline STFT / iSTFT (same bits)
 //   18 X persistent        0     0..1    1 = launches of more than 512 tiles as 512 resident workgroups pulling tiles by ticket
 //   19 X prefetch          1     0..1    1 = a resident workgroup requests its next tile's first k-tile before the current epilogue
-#define GCCNMF_TUNE_KEYS 20
+//   20 X wide_update_w     1     0..1    0 = the one-pass W update of short dictionaries at batch scale on 16 atoms per workgroup (round 4)
+#define GCCNMF_TUNE_KEYS 21
 struct GccNmfTune {
     int v[GCCNMF_TUNE_KEYS];
 };
@@ -90,3 +91,4 @@ struct GccNmfCall {
 #define gccnmf_tune_fused_k34 (gccnmf_tune.v[17])
 #define gccnmf_tune_persistent (gccnmf_tune.v[18])
 #define gccnmf_tune_prefetch (gccnmf_tune.v[19])
+#define gccnmf_tune_wide_update_w (gccnmf_tune.v[20])

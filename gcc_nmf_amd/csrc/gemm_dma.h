@@ -394,15 +394,18 @@ __device__ __forceinline__ void gemm_epilogue_update_w_full(const GemmArgs& p, i
 
 // ---- the work list of a launch ---------------------------------------------------------------------------------------------
 // A launch is an ORDERED list of work items per XCD (GemmArgs.lists = 8: XCD x = blockIdx & 7 serves list x; 1: one list), taken in
-// order -- by the hardware dispatcher (classic grid: workgroup b takes item b >> 3 of list b & 7) or by resident workgroups through
-// a ticket counter (persistent grid, below).  An item is one output tile, computed by ONE workgroup in the fixed k order, so a
+// order by the hardware dispatcher (workgroup b takes item b >> 3 of list b & 7; the experiment build can also hand them out to
+// resident workgroups through a ticket counter).  An item is one output tile, computed by ONE workgroup in the fixed k order, so a
 // file's bits depend neither on who takes an item nor on the form it has.  Three kinds, longest first:
 //   wide    512 x 64   items 0 .. len - split - 1 of a list: its chunk [list * cw, ...) of the file-major list of wide tiles
 //                      (files in the class order 0, 8, 16, ... | 1, 9, ... so that a file's tiles share one XCD's L2)
-//   halves  512 x 32   the last `split` wide tiles of the chunk as two NARROW items each (left / right 32 columns): finer grain for
-//                      the end of a launch that would otherwise leave CUs idle (host-side list-scheduling model, gemm_dma_plan)
+//   halves  512 x 32   the last `split` wide tiles of the chunk as two NARROW items each, left / right 32 columns (tuning key 9 = 2:
+//                      every tile -- a test form; choosing `split` by a list-scheduling model lost to half-height tiles, LABBOOK R5.2)
 //   ragged  512 x 32   the last column tile of a file when at most 32 of its 64 columns exist (N = 1244 = 19 x 64 + 28): half the
-//                      matrix work of the padded tile it replaces (rag = 1; chunk [list * cr, ...) of the file-major list)
+//                      matrix work of the padded tile it replaces (rag = 1; chunk [list * cr, ...) of the file-major list of these tiles)
+// The short items come LAST: the dispatcher hands blocks out in order across the eight XCDs, so a slot freed early in the middle of a
+// launch cannot take its XCD's next block while an earlier block waits elsewhere, and the co-resident pairs fall out of step -- the
+// ragged tile in its natural place costs 10 % of the launch (LABBOOK R5.3b).
 // A narrow item runs the same loop without the MFMAs of the right column block: same k order per element -> same bits.
 __host__ __device__ __forceinline__ int gemm_dma_list_file(const GemmArgs& p, int q) {      // position q in the class order -> file
     if (p.lists != 8) return q;

@@ -48,6 +48,7 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {1, 0, 2, 0},                       // 17 fused_k34
     {0, 0, 1, 1},                       // 18 persistent
     {1, 0, 1, 1},                       // 19 prefetch
+    {1, 0, 1, 1},                       // 20 wide_update_w
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
 static std::atomic<int> gccnmf_knobs_ready{0};
@@ -382,7 +383,13 @@ static int launch_update_w(float* W, const float* U, const float* rowsumH, float
 #define GCCNMF_ONEPASS(AT_, NS_) hipLaunchKernelGGL((nmf_update_w_onepass_kernel<AT_, NS_>), dim3(batch * (Kp / AT_)), dim3(256), 0, s, W, U, rowsumH, \
                                                     colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR, Wt, sWt, ldwt)
         const bool narrow = gccnmf_tune_ablate == 64;
-        if (narrow) {
+        // short dictionaries at batch scale (64 files, K = 128: the launch between the two fused GEMM launches): 32 atoms per workgroup =
+        // whole 128-byte lines per row and workgroup -- with 16 atoms every line of W and U is fetched by two workgroups (17 us for 51 MB).
+        // Only for K <= 128, where the launch forms follow the batch size anyway (a file's bits are batch-independent for K > 128).
+        const bool wide = !narrow && nsplit == 1 && !Wt && K <= 128 && (long)batch * (Kp / 32) >= 256 && gccnmf_tune_wide_update_w;
+        if (wide) {
+            GCCNMF_ONEPASS(32, 1);
+        } else if (narrow) {
             if (nsplit == 1) GCCNMF_ONEPASS(8, 1);
             else if (nsplit == 2) GCCNMF_ONEPASS(8, 2);
             else GCCNMF_ONEPASS(8, 4);
