@@ -49,12 +49,73 @@ def parse():
     p.add_argument('--skip-roofline', action='store_true')
     p.add_argument('--skip-cpu-baseline', action='store_true')
     p.add_argument('--skip-config-lines', action='store_true', help='no sub-records of the other BASELINE configurations (K = 128 batch, K sweep, 200 iterations, shared dictionary, streaming, big matrix)')
+    p.add_argument('--no-live-traffic', action='store_true', help='roofline.traffic from the recorded passes (profiles/pmc_traffic.json) instead of two child runs under rocprofv3 --pmc')
     p.add_argument('--skip-extras', action='store_true', help='sweeps: only the timed steps and the roofline kernel (no host-to-host, single-file, drop-in, CPU legs)')
     p.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='gccnmf_set_tuning(KEY, VALUE) before running (A/B experiments)')
     p.add_argument('--h-updates', type=int, default=2, help='streaming mode: KL-NMF coefficient updates per frame (W fixed)')
     p.add_argument('--mode', choices=['separate', 'shared-dictionary', 'streaming', 'time-sharded'], default='separate',
                    help="'separate' = the headline path (independent dictionary per file); 'shared-dictionary' = BASELINE config 4; 'streaming' = config 5; 'time-sharded' = ONE long mixture (--seconds, default 160 s there) sharded over frame windows, strong scaling")
     return p.parse_args()
+
+
+def live_traffic(a, timeout_s=150):
+    """HBM bytes per launch of the K1 / K3 kernel, measured NOW: two child runs of this file (10 KL-NMF iterations of the same batch on
+    one stream, nothing else) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, the
+    counter units and the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md's HBM section (KB = 1024 B; FETCH_SIZE reports half
+    of the bytes of 16 B/lane coalesced reads, so it is doubled).  Returns (record or None, note).  Never raises: a missing profiler, a
+    profiler already wrapped around this process, a child that fails or overruns `timeout_s` leave the recorded figure in place."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    roc = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(roc):
+        return None, 'rocprofv3 not found'
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER')) for k in os.environ) or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'this process already runs under a profiler'
+    res, t0 = {}, time.perf_counter()
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='gccnmf_pmc_', dir='/tmp')
+        cmd = [roc, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pass', '--',
+               sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '1', '--warmup', '0', '--iterations', '10',
+               '--files', str(a.files), '--dictionary-size', str(a.dictionary_size), '--hop', str(a.hop), '--seconds', str(a.seconds),
+               '--nmf-groups', '1', '--skip-extras', '--skip-roofline', '--skip-config-lines', '--skip-cpu-baseline', '--no-live-traffic']
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+        env['TMPDIR'] = '/tmp'
+        try:
+            p = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _o, err = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(p.pid, signal.SIGKILL)             # the process group this call started, nothing else
+                p.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return None, 'the %s pass overran %d s' % (counter, timeout_s)
+            if p.returncode != 0:
+                shutil.rmtree(d, ignore_errors=True)
+                return None, 'the %s pass exited %d: %s' % (counter, p.returncode, err.decode(errors='replace')[-200:])
+            vals = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    # K1 and K3 are the same instantiation: A stored [row][k], B not, EPI_DIV (= 1)
+                    if r['Counter_Name'] == counter and r['Kernel_Name'].startswith('void gccnmf_gemm_dma_kernel<true, false, 1,'):
+                        vals.append(float(r['Counter_Value']))
+            if not vals:
+                return None, 'no %s rows for the K1 / K3 kernel' % counter
+            res[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as ex:                              # noqa: BLE001 -- a measurement leg must not take the bench line down
+            return None, '%s pass: %r' % (counter, ex)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch_kb, n = res['FETCH_SIZE']
+    write_kb, _ = res['WRITE_SIZE']
+    return ({'hbm_bytes_per_launch': (2.0 * fetch_kb + write_kb) * 1024.0, 'fetch_size_kb_raw': fetch_kb, 'write_size_kb': write_kb,
+             'launches': n, 'seconds': time.perf_counter() - t0},
+            'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of bench.py --iterations 10 '
+            '--nmf-groups 1, mean over %d launches of gccnmf_gemm_dma_kernel<true,false,1,...> = K1 + K3); FETCH_SIZE doubled (gfx950 reports '
+            'half of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section), KB = 1024 B' % n)
 
 
 def kernel_timings(e, iterations=10, launches=20):
@@ -537,6 +598,7 @@ def main():
             # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (profiles/README.md), gfx950-corrected
             out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = pmc['source']
+            out['roofline']['traffic_algorithmic_unique_bytes'] = pmc.get('k1_algorithmic_unique_bytes')
         # one KL-NMF iteration = the four dependent GEMM launches, whole batch on ONE stream, wall time between events: includes
         # the ~40-60 us a kernel boundary costs between dependent launches (the timed steps hide those under the other file
         # group's kernels; kernel-time sums are in the rocprofv3 summaries)
@@ -647,6 +709,17 @@ def main():
         out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))
         out['gpu_vs_cpu_tdoa_equal'] = bool(e.get_tdoa_indexes()[0].tolist() == r['idx'])
 
+    if rank == 0 and world == 1 and 'roofline' in out and not slabs and not a.skip_extras and not a.no_live_traffic:
+        # LAST, with every other number already in `out` and this process idle on the device: the kernel's HBM traffic from the counters
+        torch.cuda.synchronize()
+        rec, note = live_traffic(a)
+        if rec:
+            out['roofline']['traffic_recorded'] = out['roofline']['traffic']
+            out['roofline']['traffic'] = rec['hbm_bytes_per_launch']
+            out['roofline']['traffic_source'] = note
+            out['roofline']['traffic_live'] = rec
+        else:
+            out['roofline']['traffic_live'] = {'skipped': note}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
