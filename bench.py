@@ -121,8 +121,10 @@ def live_traffic(a, timeout_s=150):
 def kernel_timings(e, iterations=10, launches=20):
     """(ms per KL-NMF iteration, ms per launch of the roofline kernel), HIP events on the stream the kernels are launched on
     (torch's current stream), whole batch per launch on one stream.
-      * the iteration: one event pair around `iterations` complete iterations (stages 1-5 back to back, as gccnmf_klnmf
-        issues them) -- event pairs around single launches add ~0.05-0.1 ms of gap each and are not used;
+      * the iteration: the library's own loop (gccnmf_klnmf, the call the timed steps make, here as ONE file group on one stream) run
+        for 3 x `iterations` and for `iterations` iterations between event pairs; the difference / (2 x iterations) is one iteration
+        without the call's set-up.  (Until round 5 this was timed through gccnmf_klnmf_stage, whose stages 4 + 5 are the UNFUSED
+        R.H^T and W-update launches: 8 % more than the loop the product runs at K = 1024.)
       * the roofline kernel (K3: R = V / (W.H), == K1 without the lazy row scale) is a pure function of V, W, H, so it is
         launched `launches` times back to back between one event pair.  Per-kernel averages of the other three launches:
         the committed rocprofv3 summary (profiles/*_g1_bench_kernel_stats.csv)."""
@@ -136,23 +138,30 @@ def kernel_timings(e, iterations=10, launches=20):
     def stage(s):
         _hip.check(lib.gccnmf_klnmf_stage(_ptr(e.V), _ptr(e.W), _ptr(e.H), _ptr(e.ws_nmf), g.F, g.N, g.K, e.batch, e.alpha,
                                           e.eps, e.klnmf_flags, s, _stream()), 'gccnmf_klnmf_stage')
+    ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(g.F, g.N, g.K, e.batch), dtype=torch.float32, device=e.V.device)
+
+    def loop(n):
+        _hip.check(lib.gccnmf_klnmf(_ptr(e.V), _ptr(e.W), _ptr(e.H), _ptr(ws), g.F, g.N, g.K, e.batch, n, e.alpha, e.eps, e.klnmf_flags,
+                                    _stream()), 'gccnmf_klnmf')
+    loop(2)
     stage(0)
     for s in range(1, 6):
         stage(s)
-    e0, e1, e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e0, e1, e2, e3, e4 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iterations):
-        for s in range(1, 6):
-            stage(s)
+    loop(3 * iterations)
     e1.record()
+    loop(iterations)
+    e4.record()
+    stage(0)
     stage(3)
     e2.record()
     for _ in range(launches):
         stage(3)
     e3.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iterations, e2.elapsed_time(e3) / launches
+    return (e0.elapsed_time(e1) - e1.elapsed_time(e4)) / (2 * iterations), e2.elapsed_time(e3) / launches
 
 
 def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen=1, backend='nccl'):
@@ -599,9 +608,10 @@ def main():
             out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = pmc['source']
             out['roofline']['traffic_algorithmic_unique_bytes'] = pmc.get('k1_algorithmic_unique_bytes')
-        # one KL-NMF iteration = the four dependent GEMM launches, whole batch on ONE stream, wall time between events: includes
-        # the ~40-60 us a kernel boundary costs between dependent launches (the timed steps hide those under the other file
-        # group's kernels; kernel-time sums are in the rocprofv3 summaries)
+        # one KL-NMF iteration = the four dependent GEMM launches of the library's own loop (W update fused into the R.H^T launch), whole
+        # batch on ONE stream: difference of two gccnmf_klnmf calls of different lengths.  The kernel trace shows the launches back to
+        # back (start of n+1 = end of n, profiles/r05o_launch_gaps.json), so this is the sum of the four kernel durations; the timed
+        # steps run two file groups on two streams and overlap the tail of one group's launch with the head of the other's.
         out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12,
                                            'frac_of_peak': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
 
