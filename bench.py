@@ -122,8 +122,8 @@ def kernel_timings(e, iterations=10, launches=20):
     """(ms per KL-NMF iteration, ms per launch of the roofline kernel), HIP events on the stream the kernels are launched on
     (torch's current stream), whole batch per launch on one stream.
       * the iteration: the library's own loop (gccnmf_klnmf, the call the timed steps make, here as ONE file group on one stream) run
-        for 3 x `iterations` and for `iterations` iterations between event pairs; the difference / (2 x iterations) is one iteration
-        without the call's set-up.  (Until round 5 this was timed through gccnmf_klnmf_stage, whose stages 4 + 5 are the UNFUSED
+        for 3 x `iterations` and for `iterations` iterations between event pairs (best of three each); the difference / (2 x iterations)
+        is one iteration without the call's set-up.  (Until round 5 this was timed through gccnmf_klnmf_stage, whose stages 4 + 5 are the UNFUSED
         R.H^T and W-update launches: 8 % more than the loop the product runs at K = 1024.)
       * the roofline kernel (K3: R = V / (W.H), == K1 without the lazy row scale) is a pure function of V, W, H, so it is
         launched `launches` times back to back between one event pair.  Per-kernel averages of the other three launches:
@@ -147,13 +147,19 @@ def kernel_timings(e, iterations=10, launches=20):
     stage(0)
     for s in range(1, 6):
         stage(s)
-    e0, e1, e2, e3, e4 = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    e2, e3 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     torch.cuda.synchronize()
-    e0.record()
-    loop(3 * iterations)
-    e1.record()
-    loop(iterations)
-    e4.record()
+    t_long, t_short = [], []
+    for _ in range(3):                      # best of three of each length: a call is a few milliseconds for a short dictionary
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        loop(3 * iterations)
+        ev[1].record()
+        loop(iterations)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_long.append(ev[0].elapsed_time(ev[1]))
+        t_short.append(ev[1].elapsed_time(ev[2]))
     stage(0)
     stage(3)
     e2.record()
@@ -161,7 +167,7 @@ def kernel_timings(e, iterations=10, launches=20):
         stage(3)
     e3.record()
     torch.cuda.synchronize()
-    return (e0.elapsed_time(e1) - e1.elapsed_time(e4)) / (2 * iterations), e2.elapsed_time(e3) / launches
+    return (min(t_long) - min(t_short)) / (2 * iterations), e2.elapsed_time(e3) / launches
 
 
 def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen=1, backend='nccl'):
@@ -362,7 +368,7 @@ def config_lines(a, e, xs, sr, n, local_rank):
         eng.upload(xs)
         dt = timed_runs(eng, steps)
         g = eng.g
-        iter_ms, k3_ms = kernel_timings(eng, iterations=5, launches=10)
+        iter_ms, k3_ms = kernel_timings(eng, iterations=10, launches=10)
         gemm_flop = 2.0 * g.F * g.K * g.N * B
         plan = int(eng.lib.gccnmf_klnmf_plan(g.F, g.N, g.K, eng.batch, eng.klnmf_flags))
         slabs = bool(plan & 4)
