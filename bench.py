@@ -451,6 +451,74 @@ def config_lines(a, e, xs, sr, n, local_rank):
     return res
 
 
+def dev1_mixture():
+    """The reference driver's own input (data/dev1_female3_liverec_130ms_1m_mix.wav, committed under tests/golden/data), converted like
+    the reference's wavread (gccNMF/wavfile.py:34-37).  The drop-in sequence computes the coherence quotient in the DRIVER's NumPy
+    (runGCCNMF.py:44), where an exactly-zero f32 bin of a synthetic file is 0/0 = NaN; real recordings do not have one."""
+    from scipy.io import wavfile
+    sr, pcm = wavfile.read(os.path.join(REPO, 'tests', 'golden', 'data', 'dev1_female3_liverec_130ms_1m_mix.wav'))
+    return (pcm.astype('float32') / 32768).T.copy()
+
+
+def dropin_sequence(x, sr, hop, K, iters=100, resident=False, repeats=5, G=None):
+    """The eight reference-named functions in the order of gccNMF/runGCCNMF.py:36-52, HOST arrays in and out of each, timed one by one
+    (best of `repeats` per function after one warm-up pass that fills the buffer pools); `driver_numpy_ms` is the NumPy the reference
+    driver itself runs between them (abs / concatenate / the coherence quotient / hsplit / mean), not part of the eight."""
+    if G is None:
+        from gcc_nmf_amd import gccNMFFunctions as G
+    names = ['computeComplexMixtureSpectrogram', 'performKLNMF', 'getAngularSpectrogram', 'estimateTargetTDOAIndexesFromAngularSpectrum',
+             'getTargetTDOAGCCNMFs', 'getTargetCoefficientMasks', 'getTargetSpectrogramEstimates', 'getTargetSignalEstimates']
+    best = dict((nm, float('inf')) for nm in names)
+    best_between, best_total = float('inf'), float('inf')
+    if hasattr(G, 'set_resident'):
+        G.set_resident(resident)
+    try:
+        for rep in range(repeats + 1):
+            t = {}
+            between = 0.0
+
+            def timed(nm, *args, **kw):
+                t0 = time.perf_counter()
+                r = getattr(G, nm)(*args, **kw)
+                t[nm] = time.perf_counter() - t0
+                return r
+            t_start = time.perf_counter()
+            X = timed('computeComplexMixtureSpectrogram', x, 1024, hop, np.hanning)
+            t0 = time.perf_counter()
+            numChannels, numFrequencies, numTime = X.shape
+            frequenciesInHz = np.linspace(0, sr / 2.0, numFrequencies)
+            V = np.concatenate(abs(X), axis=-1)
+            between += time.perf_counter() - t0
+            W, H = timed('performKLNMF', V, K, iters, 0)
+            t0 = time.perf_counter()
+            stereoH = np.array(np.hsplit(H, numChannels))
+            C = X[0] * X[1].conj() / abs(X[0]) / abs(X[1])
+            between += time.perf_counter() - t0
+            A = timed('getAngularSpectrogram', C, frequenciesInHz, 1.0, 128)
+            t0 = time.perf_counter()
+            meanA = np.mean(A, axis=-1)
+            between += time.perf_counter() - t0
+            idx = timed('estimateTargetTDOAIndexesFromAngularSpectrum', meanA, 1.0, 128, 3)
+            Gs = timed('getTargetTDOAGCCNMFs', C, 1.0, 128, frequenciesInHz, idx, W, stereoH)
+            M = timed('getTargetCoefficientMasks', Gs, 3)
+            S = timed('getTargetSpectrogramEstimates', M, X, W, stereoH)
+            y = timed('getTargetSignalEstimates', S, 1024, hop, np.hanning)
+            total = time.perf_counter() - t_start
+            if rep:
+                for nm in names:
+                    best[nm] = min(best[nm], t[nm])
+                best_between = min(best_between, between)
+                best_total = min(best_total, total)
+            del X, V, W, H, stereoH, C, A, Gs, M, S
+    finally:
+        if hasattr(G, 'set_resident'):
+            G.set_resident(False)
+    return {'mode': 'resident' if resident else 'copying', 'frames': int(numTime), 'hop': hop, 'dictionary_size': K, 'iterations': iters,
+            'ms': dict((nm, 1e3 * best[nm]) for nm in names), 'sum_of_the_eight_ms': 1e3 * sum(best.values()),
+            'driver_numpy_ms': 1e3 * best_between, 'whole_sequence_ms': 1e3 * best_total, 'tdoa': [int(i) for i in idx],
+            'y_rms': float(np.sqrt(np.mean(y.astype(np.float64) ** 2)))}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, rendezvous on
     127.0.0.1 (the container hostname may not resolve)."""
@@ -673,6 +741,15 @@ def main():
                                          'dropin_performKLNMF_ms': 1e3 * (time.perf_counter() - t1)}
         del e2
 
+    if rank == 0 and world == 1 and not a.skip_extras and (K, iters, a.seconds) == (1024, 100, 10.0):
+        # the whole drop-in sequence, function by function, host arrays in and out: the reference driver's own shape and BASELINE config 2's,
+        # in the default (copying) mode and in the opt-in resident mode of dropin.install(resident=True)
+        out['dropin_sequence'] = {
+            'what': 'the eight reference-named functions of gcc_nmf_amd.gccNMFFunctions in runGCCNMF.py:36-52 order on the dev1 mixture (10 s, the reference driver\'s input), NumPy '
+                    'arrays in and out of every call, best of 5 per function after one warm-up pass',
+            'driver_shape_hop128_K128': {'copying': dropin_sequence(dev1_mixture(), sr, 128, 128), 'resident': dropin_sequence(dev1_mixture(), sr, 128, 128, resident=True)},
+            'config2_hop256_K1024': {'copying': dropin_sequence(dev1_mixture(), sr, 256, 1024), 'resident': dropin_sequence(dev1_mixture(), sr, 256, 1024, resident=True)}}
+
     if rank == 0 and world == 1 and not a.skip_extras and not a.skip_config_lines and (K, iters, a.hop, a.seconds) == (1024, 100, 256, 10.0):
         t1 = time.perf_counter()
         out.update(config_lines(a, e, xs, sr, n, local_rank))
@@ -720,7 +797,9 @@ def main():
                 'frames_per_s': r0['frames_per_s'], 'nmf_only_frames_per_s': r0['nmf_only_frames_per_s'], 'host_cpus': r0['host_cpus'],
                 'blas_threads': max(t['num_threads'] for t in r0['thread_pools']) if r0.get('thread_pools') else None,
                 'best_frames_per_s': r0.get('best_frames_per_s'), 'best_blas_threads': r0.get('best_blas_threads'),
-                'source': 'profiles/reference_cpu_on_gpu_box.json (same file 0, same parameters; recorded once, not re-timed here)'}
+                'recorded': r0.get('recorded', 'round 3'),
+                'source': 'profiles/reference_cpu_on_gpu_box.json (same file 0, same parameters; the unmodified reference cannot travel with the '
+                          'repository, so it is timed in a builder session with the checkout staged, not in this run)'}
         y0 = e.y[0].cpu().numpy()
         out['gpu_vs_cpu_waveform_rms'] = float(np.sqrt(np.mean((y0.astype(np.float64) - r['y']) ** 2)))
         out['gpu_vs_cpu_tdoa_equal'] = bool(e.get_tdoa_indexes()[0].tolist() == r['idx'])

@@ -1,0 +1,222 @@
+"""Host <-> device staging of the reference-named functions (gccNMFFunctions.py, librosaSTFT.py): plumbing only.
+
+Every named function takes NumPy arrays and returns NumPy arrays (gccNMF/runGCCNMF.py:36-52 passes the result of one to the
+next through host memory).  What this module keeps off the per-call path:
+
+* **device buffers** come from a per-(tag, shape, corner) pool of zero-initialised tensors instead of ``torch.zeros`` per call.  A
+  padded buffer is only ever written in its logical corner (uploads) or by kernels that leave the padding alone, so the zero
+  padding the kernels rely on survives re-use (the same invariant GCCNMFEngine's buffers live by);
+* **uploads** are one contiguous memcpy into a page-locked block, one DMA, and a strided device copy into the padded corner;
+* **downloads** are compacted on the device (padded -> the reference's contiguous shape), DMA'd into a page-locked block, and the
+  ndarray that is returned is BASED on that block: no host copy.  The block returns to the pool when the last array (or view) over it
+  is garbage-collected;
+* **resident mode** (``set_resident(True)`` / ``dropin.install(resident=True)``): the device image behind every array a named
+  function RETURNS is kept, keyed by the ndarray object, and the array is returned read-only -- identity then implies unchanged
+  contents -- so that when the same object comes back as an argument (X, W, the scores, the masks, the spectrogram estimates in
+  runGCCNMF.py:36-52) the re-upload is skipped.  Default mode: nothing is remembered, outputs are writable, every argument is
+  uploaded.
+
+Not thread-safe (like the reference's module-level NumPy RNG state); one pool per process.
+"""
+import weakref
+
+import numpy as np
+import torch
+
+_TORCH_DTYPE = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.complex64): torch.complex64,
+                np.dtype(np.uint8): torch.uint8, np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16}
+
+_GRANULE = 1 << 16                       # page-locked blocks are pooled by size rounded up to 64 KiB
+_PINNED_FREE = {}                        # rounded bytes -> [uint8 pinned tensors]
+_PINNED_FREE_BYTES = [0]
+PINNED_POOL_LIMIT = 1 << 30              # free page-locked bytes kept for re-use; beyond it blocks are simply freed
+_DEVICE_FREE = {}                        # (tag, shape, corner, dtype, device index) -> [tensors]
+_RESIDENT = {}                           # id(ndarray) -> _Resident
+_resident_mode = [False]
+
+
+def set_resident(on):
+    """Opt in to / out of resident mode (module docstring).  Switching off forgets every remembered device image."""
+    _resident_mode[0] = bool(on)
+    if not on:
+        for rec in list(_RESIDENT.values()):
+            rec.drop()
+    return _resident_mode[0]
+
+
+def resident_mode():
+    return _resident_mode[0]
+
+
+def _take_pinned(nbytes):
+    size = max(_GRANULE, -(-int(nbytes) // _GRANULE) * _GRANULE)
+    free = _PINNED_FREE.get(size)
+    if free:
+        _PINNED_FREE_BYTES[0] -= size
+        return free.pop()
+    return torch.empty(size, dtype=torch.uint8).pin_memory()
+
+
+def _give_pinned(t):
+    size = t.numel()
+    if _PINNED_FREE_BYTES[0] + size <= PINNED_POOL_LIMIT:
+        _PINNED_FREE.setdefault(size, []).append(t)
+        _PINNED_FREE_BYTES[0] += size
+
+
+class _HostBlock(object):
+    """Owner of one page-locked block; NumPy arrays are based on it through __array_interface__ and keep it alive (views collapse
+    their .base onto the first array over the block, which holds this object).  Back to the pool on the last reference's death."""
+
+    def __init__(self, nbytes):
+        self.tensor = _take_pinned(nbytes)
+        self.__array_interface__ = {'shape': (self.tensor.numel(),), 'typestr': '|u1', 'data': (self.tensor.data_ptr(), False),
+                                    'version': 3}
+
+    def __del__(self):
+        try:
+            _give_pinned(self.tensor)
+        except Exception:              # interpreter shutdown
+            pass
+
+
+def host_array(shape, dtype):
+    """(ndarray, torch view) over a fresh page-locked block: copy_ into the torch view, hand the ndarray to the caller."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    block = _HostBlock(nbytes)
+    arr = np.asarray(block)[:nbytes].view(dtype).reshape(shape)
+    t = block.tensor[:nbytes].view(_TORCH_DTYPE[dtype]).view(shape)
+    return arr, t
+
+
+class _Resident(object):
+    """The device image(s) behind one returned ndarray."""
+
+    def __init__(self, arr, kind, device, tensors, leases, meta):
+        self.kind, self.device, self.tensors, self.leases, self.meta = kind, device, tensors, leases, meta
+        self.key = id(arr)
+        self.ref = weakref.ref(arr, self._dead)
+
+    def _dead(self, _ref):
+        self.drop()
+
+    def drop(self):
+        if _RESIDENT.get(self.key) is self:
+            del _RESIDENT[self.key]
+        for key, t in self.leases:
+            _DEVICE_FREE.setdefault(key, []).append(t)
+        self.leases = []
+
+
+def lookup(arr, kind, device):
+    """The remembered device image of `arr` if it is an array this process returned as `kind`, untouched since."""
+    if not _resident_mode[0]:
+        return None
+    rec = _RESIDENT.get(id(arr))
+    if rec is None or rec.ref() is not arr or rec.kind != kind or rec.device != device or arr.flags.writeable:
+        return None
+    return rec
+
+
+class Scope(object):
+    """One named-function call: leases of pooled buffers, returned to the pools in finish() unless handed to a resident record."""
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.current_stream(device)
+        self._dev = []               # [(key, tensor)]
+        self._pinned = []
+        self._kept = set()
+
+    def dev(self, tag, shape, dtype=torch.float32, corner=None):
+        """Zero-initialised pooled device tensor.  `corner` = the logical extent uploads write (part of the key: a buffer is never
+        re-used for a different corner, so stale data can never sit in what another call treats as zero padding)."""
+        shape = tuple(int(s) for s in shape)
+        key = (tag, shape, None if corner is None else tuple(int(c) for c in corner), dtype, self.device.index)
+        free = _DEVICE_FREE.get(key)
+        t = free.pop() if free else torch.zeros(shape, dtype=dtype, device=self.device)
+        self._dev.append((key, t))
+        return t
+
+    def upload(self, host, tag, dtype=None):
+        """Contiguous host array -> contiguous device tensor of the same shape (through a page-locked block, asynchronous)."""
+        host = np.asarray(host)
+        dtype = np.dtype(dtype or host.dtype)
+        nbytes = host.size * dtype.itemsize
+        pin = _take_pinned(nbytes)
+        self._pinned.append(pin)
+        view = pin[:nbytes].view(_TORCH_DTYPE[dtype]).view(host.shape)
+        np.copyto(view.numpy(), host, casting='unsafe')           # the one host pass (converts dtype / gathers strides if it must)
+        d = self.dev('up:' + tag, host.shape, _TORCH_DTYPE[dtype])
+        d.copy_(view, non_blocking=True)
+        return d
+
+    def download(self, dev_view, shape=None, dtype=None):
+        """Device tensor (any strides; dtype converted on the device) -> ndarray based on a page-locked block.  Asynchronous: the
+        array is valid after finish()."""
+        shape = tuple(dev_view.shape) if shape is None else tuple(shape)
+        np_dtype = np.dtype(dtype) if dtype is not None else {v: k for k, v in _TORCH_DTYPE.items()}[dev_view.dtype]
+        tdt = _TORCH_DTYPE[np_dtype]
+        if not dev_view.is_contiguous() or dev_view.dtype != tdt:
+            comp = self.dev('down', (dev_view.numel(),), tdt)
+            comp.view(dev_view.shape).copy_(dev_view)                   # one gather / conversion kernel at HBM speed
+            dev_view = comp
+        arr, t = host_array(shape, np_dtype)
+        t.copy_(dev_view.view(shape), non_blocking=True)
+        return arr
+
+    def remember(self, arr, kind, tensors, meta=None):
+        """Resident mode: keep `tensors` (a dict of device tensors leased in this scope) as the device image of `arr`."""
+        if not _resident_mode[0]:
+            return arr
+        ids = set(id(t) for t in tensors.values())
+        leases = [(k, t) for k, t in self._dev if id(t) in ids]
+        self._kept |= ids
+        arr.flags.writeable = False
+        old = _RESIDENT.get(id(arr))
+        if old is not None:
+            old.drop()
+        _RESIDENT[id(arr)] = _Resident(arr, kind, self.device, tensors, leases, meta or {})
+        return arr
+
+    def finish(self):
+        self.stream.synchronize()
+        for key, t in self._dev:
+            if id(t) not in self._kept:
+                _DEVICE_FREE.setdefault(key, []).append(t)
+        for pin in self._pinned:
+            _give_pinned(pin)
+        self._dev, self._pinned = [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.finish()
+        return False
+
+
+_CONSTANTS = {}
+
+
+def constant(key, make, device):
+    """Device copy of an input-independent table (window, twiddles, steering cos / sin), built once per (key, device)."""
+    k = (key, device.index)
+    t = _CONSTANTS.get(k)
+    if t is None:
+        if len(_CONSTANTS) > 64:
+            _CONSTANTS.clear()
+        t = _CONSTANTS[k] = torch.from_numpy(np.ascontiguousarray(make())).to(device)
+    return t
+
+
+def clear():
+    """Drop every pooled buffer and remembered image (tests; memory pressure)."""
+    for rec in list(_RESIDENT.values()):
+        rec.drop()
+    _DEVICE_FREE.clear()
+    _PINNED_FREE.clear()
+    _PINNED_FREE_BYTES[0] = 0
+    _CONSTANTS.clear()

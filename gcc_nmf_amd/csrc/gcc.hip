@@ -171,6 +171,19 @@ __global__ __launch_bounds__(256) void gcc_coherence_kernel(const float2* __rest
     Cb[plane] = im;
 }
 
+// V = concatenate(abs(X), axis=-1) (runGCCNMF.py:40) from an existing spectrogram: V[f][c*T + t] = |X[c][f][t]|, the same hypotf as the
+// STFT epilogue (fft.hip), which is where the pipeline gets V from; this standalone form serves the host-array API
+// (getTargetSpectrogramEstimates called with a spectrogram that did not come from this process's STFT).
+// grid = (ceil(T/256), F, batch * 2)
+__global__ __launch_bounds__(256) void gcc_magnitude_kernel(const float2* __restrict__ X, int Fp, int T, int Tp, int Np,
+                                                            float* __restrict__ V) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z >> 1, c = blockIdx.z & 1;
+    if (t >= T) return;
+    const float2 x = X[((long)b * 2 + c) * Fp * Tp + (long)f * Tp + t];
+    V[(long)b * Fp * Np + (long)f * Np + c * T + t] = hypotf(x.x, x.y);
+}
+
 // Hm[k][(i*2+c)*Tp + t] = H[k][c*T + t] if argmax[k][t] == i else 0 (H_c * M_i, gccNMFFunctions.py:150).
 // One thread = four consecutive frames of one (target, channel) block: one 16-byte store (the write is 4/5 of this kernel's traffic:
 // 1 GB per 64-file step), the arg-max as one 4-byte load; H_c starts at column c*T, which is only 4-byte aligned: scalar loads (L2).
@@ -318,6 +331,16 @@ int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* s
     GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
     hipLaunchKernelGGL(gcc_coherence_kernel, dim3(gccnmf_ceil_div(T, 256), F, batch), dim3(256), 0, (hipStream_t)stream,
                        (const float2*)X, p.Fp, T, p.Tp, CC);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+int gccnmf_magnitude(const float* X, int F, int T, int batch, float* V, void* stream) {
+    GCCNMF_ENTER();
+    if (!X || !V || F < 2 || T < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    GccNmfPitches p = gccnmf_make_pitches(F, T, 1);
+    hipLaunchKernelGGL(gcc_magnitude_kernel, dim3(gccnmf_ceil_div(T, 256), F, batch * 2), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)X, p.Fp, T, p.Tp, p.Np, V);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

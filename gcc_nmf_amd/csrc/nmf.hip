@@ -892,7 +892,7 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
     const bool split_wh = single_file_split(g, batch, g.Kp, gccnmf_tune_wh_splits);      // the round-3 latency path: one file's reductions as parts
     const bool split_rht = single_file_split(g, batch, g.Np, gccnmf_tune_rht_splits);
 #else
-    constexpr bool split_wh = false, split_rht = false;
+    constexpr bool split_rht = false;              // the split-K path is compiled out of the product library
 #endif
     const int xcd = ((flags & 1) ? 0 : 1) | ((flags & 4) ? 2 : 0);      // bit 1: another file group's launches run beside these
     const int vec_grid = batch * (g.Kp / 16);

@@ -21,21 +21,29 @@ _ALIASES = {
 }
 
 
-def install():
+def install(resident=False):
     """After this call ``from gccNMFFunctions import *`` / ``from gccNMF.gccNMFFunctions import ...`` bind the
-    MI355X implementations.  Returns the replacement module."""
+    MI355X implementations.  Returns the replacement module.
+
+    ``resident=True`` (opt-in): every array a named function returns is read-only and keeps its device image while it lives; passing the
+    same object on to the next function -- what runGCCNMF.py:36-52 does with X, W, the scores, the masks and the spectrogram estimates --
+    then skips the re-upload (gcc_nmf_amd/_staging.py).  Default: writable outputs, every argument uploaded, as in earlier rounds."""
     import importlib
     for alias, target in _ALIASES.items():
         sys.modules[alias] = importlib.import_module(target)
+    sys.modules['gccNMFFunctions'].set_resident(resident)
     return sys.modules['gccNMFFunctions']
 
 
 def uninstall():
+    mod = sys.modules.get('gccNMFFunctions')
+    if mod is not None and hasattr(mod, 'set_resident'):
+        mod.set_resident(False)
     for alias in _ALIASES:
         sys.modules.pop(alias, None)
 
 
-def run_reference_driver(reference_root, workdir=None):
+def run_reference_driver(reference_root, workdir=None, resident=False):
     """Execute ``<reference_root>/gccNMF/runGCCNMF.py`` byte-for-byte unchanged (as ``__main__``) against this
     package.  The driver reads ``../data/<prefix>_mix.wav`` and writes ``../data/<prefix>_sim_N.wav`` relative to
     its working directory, so it runs from a scratch copy of ``data/``.  Returns the directory holding the outputs."""
@@ -50,7 +58,7 @@ def run_reference_driver(reference_root, workdir=None):
     if not os.path.isdir(data):
         shutil.copytree(os.path.join(reference_root, 'data'), data)
     os.environ.setdefault('MPLBACKEND', 'Agg')              # gccNMFPlotting imports matplotlib
-    install()
+    install(resident=resident)
     old_cwd, old_path = os.getcwd(), list(sys.path)
     try:
         os.chdir(cwd)

@@ -8,7 +8,7 @@ the transform itself has no CPU implementation here.
 import numpy as np
 import torch
 
-from . import _hip
+from . import _hip, _staging
 from .engine import Geometry, padded, fft_twiddles, _ptr, _stream, num_frames
 
 
@@ -131,8 +131,16 @@ def frame(y, frame_length=2048, hop_length=512):
     return np.lib.stride_tricks.as_strided(y, shape=(frame_length, n_frames), strides=(y.itemsize, hop_length * y.itemsize))
 
 
-def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
-    """One packed complex FFT per frame carries both real signals (y1 may be None)."""
+def _fft_tables(w, n_fft, dev):
+    wf = np.asarray(w, np.float64).astype(np.float32)
+    dwin = _staging.constant(('window', n_fft, wf.tobytes()), lambda: wf, dev)
+    dtw = _staging.constant(('twiddle', n_fft), lambda: fft_twiddles(n_fft), dev)
+    return dwin, dtw
+
+
+def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center, remember=False):
+    """One packed complex FFT per frame carries both real signals (y1 may be None).  `remember`: in resident mode the device
+    spectrogram and its magnitude V (the STFT epilogue's) stay behind the returned array (_staging)."""
     _check_n_fft(n_fft)
     w = _window_vector(window, win_length, n_fft)
     chans = []
@@ -153,22 +161,29 @@ def _stft_device(y0, y1, n_fft, hop_length, win_length, window, center):
     lib, dev = _hip.lib(), _device()
     F = n_fft // 2 + 1
     g = Geometry(F, T, 1)
-    x = torch.zeros((2, n), dtype=torch.float32, device=dev)
-    for c, y in enumerate(chans):
-        x[c] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
     if int(n_fft) not in RADIX2_N_FFT:
+        x = torch.zeros((2, n), dtype=torch.float32, device=dev)
+        for c, y in enumerate(chans):
+            x[c] = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
         basis = torch.from_numpy(dft_basis(w, n_fft, g.Fp)).to(dev)
         ws = torch.zeros(lib.gccnmf_dft_workspace_floats(n_fft, T, 2), dtype=torch.float32, device=dev)
         X = torch.zeros((2, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
         _hip.check(lib.gccnmf_stft_dft(_ptr(x), n, n, n_fft, hop_length, T, 2, _ptr(basis), _ptr(ws), _ptr(X), _stream()), 'gccnmf_stft_dft')
         out = torch.view_as_complex(X)[:, :F, :T].cpu().numpy()
         return out if y1 is not None else out[0]
-    dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
-    dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
-    X = torch.zeros((2, g.Fp, g.Tp, 2), dtype=torch.float32, device=dev)
-    _hip.check(lib.gccnmf_stft_stereo(_ptr(x), 2 * n, n, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), _ptr(X), 0, 0,
-                                      _stream()), 'gccnmf_stft_stereo')
-    out = torch.view_as_complex(X)[:, :F, :T].cpu().numpy()
+    dwin, dtw = _fft_tables(w, n_fft, dev)
+    with _staging.Scope(dev) as sc:
+        x = sc.dev('x', (2, n), corner=(len(chans), n))                 # one signal: the second row stays zero
+        for c, y in enumerate(chans):
+            x[c].copy_(sc.upload(y, 'x%d' % c, np.float32))
+        X = sc.dev('X', (2, g.Fp, g.Tp, 2), corner=(F, T))
+        V = sc.dev('V', (g.Fp, g.Np), corner=(F, g.N)) if remember and _staging.resident_mode() else None
+        _hip.check(lib.gccnmf_stft_stereo(_ptr(x), 2 * n, n, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), _ptr(X), _ptr(V), 0,
+                                          _stream()), 'gccnmf_stft_stereo')
+        nsig = 2 if y1 is not None else 1
+        out = sc.download(torch.view_as_complex(X)[:nsig, :F, :T])
+        if V is not None and nsig == 2:
+            sc.remember(out, 'X', dict(X=X, V=V), dict(F=F, T=T))
     return out if y1 is not None else out[0]
 
 
@@ -181,8 +196,9 @@ def stft(y, n_fft=2048, hop_length=None, win_length=None, window=None, center=Tr
     return np.asfortranarray(_stft_device(y, None, n_fft, hop_length, win_length, window, center).astype(dtype))
 
 
-def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
-    """specs: (nsig, F, T) complex -> (nsig, L) float32."""
+def _istft_device(specs, hop_length, win_length, window, center, gain=1.0, device_spec=None):
+    """specs: (nsig, F, T) complex -> (nsig, L) float32.  `device_spec`: the padded device image [nsig][Fp][Tp] of `specs` when it is
+    already in HBM (resident mode, nsig even)."""
     specs = np.asarray(specs)
     nsig, F, T = specs.shape
     n_fft = 2 * (F - 1)
@@ -191,10 +207,10 @@ def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
     lib, dev = _hip.lib(), _device()
     g = Geometry(F, T, 1)
     npad = nsig + (nsig & 1)
-    host = np.ascontiguousarray(specs.astype(np.complex64)).view(np.float32).reshape(nsig, F, T, 2)
-    dS = padded(host, (npad, g.Fp, g.Tp, 2), dev)
+    L = n_fft + hop_length * (T - 1) - (n_fft if center else 0)
     if int(n_fft) not in RADIX2_N_FFT:
-        L = n_fft + hop_length * (T - 1) - (n_fft if center else 0)
+        host = np.ascontiguousarray(specs.astype(np.complex64)).view(np.float32).reshape(nsig, F, T, 2)
+        dS = padded(host, (npad, g.Fp, g.Tp, 2), dev)
         if L < 1:
             return np.zeros((nsig, 0), np.float32)
         ibasis = torch.from_numpy(idft_basis(w, n_fft, g.Fp)).to(dev)
@@ -203,16 +219,21 @@ def _istft_device(specs, hop_length, win_length, window, center, gain=1.0):
         _hip.check(lib.gccnmf_istft_dft(_ptr(dS), npad, n_fft, hop_length, T, _ptr(ibasis), np.float32(gain), 1 if center else 0, _ptr(ws),
                                         _ptr(y), _stream()), 'gccnmf_istft_dft')
         return y[:nsig].cpu().numpy()
-    dwin = torch.from_numpy(np.asarray(w, np.float64).astype(np.float32)).to(dev)
-    dtw = torch.from_numpy(fft_twiddles(n_fft)).to(dev)
-    frames = torch.zeros((npad, T, n_fft), dtype=torch.float32, device=dev)
-    L = n_fft + hop_length * (T - 1) - (n_fft if center else 0)
     if L < 1:
         return np.zeros((nsig, 0), np.float32)
-    y = torch.zeros((npad, L), dtype=torch.float32, device=dev)
-    _hip.check(lib.gccnmf_istft_ola(_ptr(dS), npad, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), np.float32(gain),
-                                    1 if center else 0, _ptr(frames), _ptr(y), _stream()), 'gccnmf_istft_ola')
-    return y[:nsig].cpu().numpy()
+    dwin, dtw = _fft_tables(w, n_fft, dev)
+    with _staging.Scope(dev) as sc:
+        if device_spec is not None and npad == nsig:
+            dS = device_spec
+        else:
+            dS = sc.dev('spec', (npad, g.Fp, g.Tp, 2), corner=(nsig, F, T))
+            torch.view_as_complex(dS)[:nsig, :F, :T].copy_(sc.upload(specs, 'spec', np.complex64))
+        frames = sc.dev('frames', (npad, T, n_fft))                      # scratch of the two-kernel form: every frame t < T is written
+        y = sc.dev('y', (npad, L))
+        _hip.check(lib.gccnmf_istft_ola(_ptr(dS), npad, n_fft, hop_length, T, 1, _ptr(dwin), _ptr(dtw), np.float32(gain),
+                                        1 if center else 0, _ptr(frames), _ptr(y), _stream()), 'gccnmf_istft_ola')
+        out = sc.download(y[:nsig])
+    return out
 
 
 def istft(stft_matrix, hop_length=None, win_length=None, window=None, center=True, dtype=np.float32):

@@ -239,6 +239,10 @@ int gccnmf_argmax_targets(const float* scores, int K, int T, int S, int batch, u
  * gets CC from gccnmf_stft_stereo's epilogue instead. */
 int gccnmf_coherence(const float* X, int F, int T, int batch, float* CC, void* stream);
 
+/* V = concatenate(abs(X), axis=-1) (runGCCNMF.py:40) from an existing spectrogram X [batch][2][Fp][Tp] -> V [batch][Fp][Np], columns
+ * c*T + t; the pipeline gets V from gccnmf_stft_stereo's epilogue instead (same hypotf). */
+int gccnmf_magnitude(const float* X, int F, int T, int batch, float* V, void* stream);
+
 /* Masked reconstruction S[i,c] = (W . (H_c * M_i)) * X_c/|X_c|.  Replaces
  * getTargetSpectrogramEstimates (gccNMFFunctions.py:145-151).
  *   the mask is either `argmax` [batch][Kp][Tp] uint8 (one-hot masks, the device pipeline) or, when
