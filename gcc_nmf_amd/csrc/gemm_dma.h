@@ -100,10 +100,9 @@ __device__ __forceinline__ void gemm_tie(T& v) { asm volatile("" : "+v"(v)); }
 // included), so the compiler sees no control flow and its register allocation of the main loop is untouched.
 __device__ __forceinline__ void gemm_barrier_arrive(unsigned counter_byte_addr) {
     unsigned long long saved;
-    const unsigned one = 1u;
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved)
-                 : "v"(counter_byte_addr), "v"(one)
+                 : "v"(counter_byte_addr), "v"(1u)
                  : "memory");
 }
 // The wait in two parts: the counter is READ a few MFMAs ahead (no wait), and CHECKED where the hand-over is needed -- in the
@@ -415,6 +414,27 @@ __host__ __device__ __forceinline__ int gemm_dma_list_file(const GemmArgs& p, in
 }
 __host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int list, int t, int& file, int& tm, int& col0, int& nw) {
     const int wt = p.tiles_m * p.wide_n;                      // wide tiles per file
+    if (p.whole_files) {
+        // chained launches: every producer and consumer of a file must run on ONE XCD in every GEMM of the iteration, whatever the batch
+        // size: list x holds the files x, x + 8, ... whole, each file's tm-major wide tiles followed by its ragged items.  (A plain
+        // launch cuts the file-major list into equal eighths and keeps the short items at the end of each list: LABBOOK R5.3b.  A consumer
+        // that needs the WHOLE file -- K4 after K3 -- would wait for an item at the very end of the producer's list.)
+        const int per = p.tiles_m * p.tiles_n;
+        const int ql = t / per, w = t - ql * per;
+        const int fi = list + 8 * ql;
+        if (fi >= p.batch) return false;
+        if (w < wt) {
+            tm = w / p.wide_n;
+            col0 = (w - tm * p.wide_n) * 64;
+            nw = 2;
+        } else {
+            tm = w - wt;
+            col0 = (p.tiles_n - 1) * 64;
+            nw = 1;
+        }
+        file = fi + p.file0;
+        return true;
+    }
     const int base_w = list * p.cw;
     const int len = min(max(p.batch * wt - base_w, 0), p.cw), s = min(p.split, len);
     int q;
@@ -453,8 +473,101 @@ __host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int li
 // is empty -- work-conserving whatever the items cost; the ticket of the NEXT item is taken at the start of the current one, and the
 // next tile's first LDS-DMA pieces are issued BEFORE the current tile's epilogue (p.prefetch), so a workgroup's matrix pipe does not
 // wait for a prologue between two tiles.  The last workgroup to leave resets the counters (the next launch on the stream finds zeros).
-template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW>
-__global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
+// ---- chained launches: hand-over between the GEMMs of an iteration inside ONE launch ---------------------------------------------
+// The four GEMMs of a KL-NMF iteration depend on each other tile by tile or file by file only (LABBOOK R5.5), and with the XCD-affine
+// work lists every producer and consumer of a file run on the same XCD.  A chained launch holds the item lists of several GEMMs back
+// to back (per XCD: stage 0's list, then stage 1's, ...); the hardware dispatcher hands workgroups out in order, so every producer
+// is resident (or finished) before its consumer starts, and a consumer that finds its operands not ready spins on a counter:
+//   producer   after its last store: s_waitcnt vmcnt(0) (its stores have reached the XCD's L2), workgroup barrier, ONE agent-scope
+//              atomic add on the counter of what it produced -- no L2 write-back (`buffer_wbl2`): the consumer reads the same L2
+//   consumer   thread 0 polls the counter past the L1 (agent-scope load); then buffer_inv sc1 (this CU's L1 may hold lines of the
+//              operand's previous contents) and only then the first operand fetch
+// A poll gives up after GEMM_SYNC_TIMEOUT (a dispatcher that is not in order, a workgroup on the wrong XCD): it raises *error and goes
+// on, the call's outputs are then poisoned by the caller -- never a hang.
+struct GemmSync {
+    unsigned* wait_cnt;                  // consumer side: nullptr = the stage has no in-launch producer
+    unsigned* sig_cnt;                   // producer side: nullptr = nothing waits for this stage inside the launch
+    int wait_stride, sig_stride;         // counters per file
+    int wait_per_tile, sig_per_tile;     // 1: counter (file, column tile), the producer adds the item's 32-column blocks (nw); 0: counter (file), + 1 per item
+    unsigned wait_need, wait_need_last;  // producer counts PER ITERATION the consumer waits for; _last: for the consumer's column tile `last_tile`
+    int last_tile;
+    int wait_lag;                        // 0: the producer runs in the same iteration (waits for need x (it + 1)); 1: in the previous one (need x it: K4 -> K1)
+    int local;                           // 1: counter traffic stays in the XCD's L2 (atomic add without a scope, polls that only bypass the L1): ~0.5 us per
+                                         //    poll instead of ~3 us for the agent-scope pair, which goes to the memory side
+    unsigned* error;
+    unsigned* xcc_seen;                  // [list]: bit x set by every workgroup of the list that ran on XCC x -- checked after the call (one bit per list)
+};
+#define GEMM_SYNC_TIMEOUT 2000000LL      // s_memrealtime ticks (100 MHz): 20 ms, a whole chained launch is ~1-3 ms
+
+__device__ __forceinline__ unsigned gemm_sync_peek(const unsigned* counter, int local) {
+    unsigned v;
+    if (local) asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(counter) : "memory");
+    else asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(counter) : "memory");
+    return v;
+}
+// it: the iteration this workgroup belongs to, counted from the zeroing of the counters.
+// ticket_counter != nullptr (resident chained grid): thread 0 also CLAIMS the workgroup's next item here -- a returning agent-scope atomic add
+// issued together with the first poll, so that its round trip (~3 us across eight XCDs) costs nothing extra -- and leaves it in *s_next.
+__device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int col0, int tid, int it, int list, unsigned* ticket_counter = nullptr,
+                                               int* s_next = nullptr) {
+    if (y.xcc_seen && tid == 0) {        // the hand-over relies on a list's workgroups sharing ONE XCD's L2: recorded here (no return, no wait), judged after the call
+        const unsigned bit = 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);      // HW_REG_XCC_ID
+        asm volatile("global_atomic_or %0, %1, off sc1" : : "v"(y.xcc_seen + list), "v"(bit) : "memory");
+    }
+    if (y.wait_cnt) {                    // (kernel argument: wave-uniform)
+        if (tid == 0) {
+            unsigned claimed = 0;
+            if (ticket_counter) asm volatile("global_atomic_add %0, %1, %2, off sc0 sc1" : "=&v"(claimed) : "v"(ticket_counter), "v"(1u) : "memory");
+            const int tile = col0 >> 6;
+            const unsigned* c = y.wait_cnt + (long)file * y.wait_stride + (y.wait_per_tile ? tile : 0);
+            const unsigned need = ((y.wait_per_tile && tile == y.last_tile) ? y.wait_need_last : y.wait_need) * (unsigned)(it + 1 - y.wait_lag);
+            const long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned seen = gemm_sync_peek(c, y.local);                // (its s_waitcnt vmcnt(0) also covers the claim)
+            if (ticket_counter) {
+                gemm_tie(claimed);
+                *s_next = (int)claimed;
+            }
+            while (seen < need) {
+                __builtin_amdgcn_s_sleep(16);
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GEMM_SYNC_TIMEOUT) {
+                    *y.error = 1u;
+                    break;
+                }
+                seen = gemm_sync_peek(c, y.local);
+            }
+        }
+        __syncthreads();
+        asm volatile("buffer_inv sc1" ::: "memory");
+    }
+}
+// all waves: after the item's last store
+__device__ __forceinline__ void gemm_sync_signal(const GemmSync& y, int file, int col0, int nw, int tid) {
+    if (y.sig_cnt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* c = y.sig_cnt + (long)file * y.sig_stride + (y.sig_per_tile ? (col0 >> 6) : 0);
+            const unsigned n = y.sig_per_tile ? (unsigned)nw : 1u;
+            if (y.local) asm volatile("global_atomic_add %0, %1, off" : : "v"(c), "v"(n) : "memory");
+            else asm volatile("global_atomic_add %0, %1, off sc1" : : "v"(c), "v"(n) : "memory");
+        }
+    }
+}
+
+// LDS of one workgroup of the throughput tile: two staging buffers (A | B | A tail-row chunk | B row-scale chunk), the lean epilogue's row
+// factors, the split barrier's counter, the persistent grid's ticket slots
+template <int TM>
+struct GemmDmaLds {
+    static constexpr int SBUF = 128 * TM * 16 + 64 * 16 + 16 + 16;
+};
+
+// One workgroup of the throughput tile: items t, (persistent grid: further tickets) of list `list`.
+// OPAQUE: the caller runs this inside a loop of its own (resident chained grid): every per-lane value is derived from an opaque copy of the
+// thread index, so that none of them is a loop invariant of THAT loop (they would be kept live -- spilled -- across all four tile programs)
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW, bool OPAQUE = false>
+__device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* const smem, float* const s_rowvec, unsigned* const s_arrivals_p,
+                                                   int* const s_ticket, const int list, int t, const GemmSync& sync, const int sync_it = 0,
+                                                   const bool trace_on = true, unsigned* const claim_counter = nullptr, int* const s_claim = nullptr) {
     static_assert(TM == 4 || TM == 2, "");
     static_assert(TM == 4 || EPI != EPI_UPDW, "the fused W update owns all rows of its atoms: full-height tiles only");
     static_assert(!NARROW || (EPI != EPI_UPDW && TM == 4), "narrow items: full-height tiles with an element-wise epilogue");
@@ -462,15 +575,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     constexpr int NA = 2 * TM;                                         // 1 KB LDS-DMA pieces of the A tile per wave
     constexpr int SA = BM * BK, SB = BN * BK;
     constexpr int SBUF = SA + SB + BK + BK;          // A | B | A tail-row chunk | B row-scale chunk
+    static_assert(SBUF == GemmDmaLds<TM>::SBUF, "");
     constexpr bool SCALE = !B_KC && (EPI == EPI_DIV || EPI == EPI_STORE);   // K1 (R = V / (W.(s*H))) carries a lazy row scale on its B operand
-    __shared__ __attribute__((aligned(16))) float smem[2 * SBUF];
-    __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * BM : 4];   // lean epilogue row factors
-    __shared__ unsigned s_arrivals;                  // split barrier of the main loop: 4 arrivals per k-tile
-    __shared__ int s_ticket[2];                      // persistent grid: the next item of this workgroup (alternating slots)
+    unsigned& s_arrivals = *s_arrivals_p;            // split barrier of the main loop: 4 arrivals per k-tile
 
     // Per-lane values are RE-DERIVED per item from an opaque copy of the thread index (gemm_opaque_tid): as loop invariants of the item
     // loop they would stay live across the epilogue, whose 128 accumulators + two tile pairs of inputs leave no registers for them.
-    int tid = threadIdx.x, lane = tid & 63;
+    int tid = OPAQUE ? gemm_opaque_tid() : (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
     const int wm = wave, wn = 0;
     int l31 = lane & 31, hh = lane >> 5;
@@ -479,8 +590,6 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 #else
     constexpr bool persistent = false;          // the resident-workgroup form is an experiment build (make EXPERIMENTS=1): measured slower, see LABBOOK.md
 #endif
-    const int list = p.lists == 8 ? (int)(blockIdx.x & 7) : 0;
-    int t = p.lists == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;            // first item: static (the counter starts behind the resident workgroups)
 
     // ---- per-item state (set by take_item) ----
     int file = 0, tm = 0, col0 = 0, nw = 2, row0 = 0;
@@ -583,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     gemm_f32x4 sc0 = zero4, sc1 = zero4, t4 = zero4, tb4 = zero4, ts4 = zero4, rs4 = zero4;
     gemm_f32x2 tbxy = {0.f, 0.f}, tbzw = {0.f, 0.f};
 
-    const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)&s_arrivals;
+    const unsigned arrivals_addr = (unsigned)(size_t)(gemm_lds_ptr)s_arrivals_p;
     // per-lane byte offsets inside a staging buffer (q = 0 / q = 1 chunk of this lane half)
     unsigned oA0 = 0, oA1 = 0, oB0 = 0, oB1 = 0, oTB = 0, oRS = 0;
     const int tg = wave;                                           // tail row: 4 thread groups (= waves) x 4 reduction steps each
@@ -816,14 +925,14 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     long long* trace_row = nullptr;
     while (have) {
         const int vb = p.lists == 8 ? 8 * t + list : t;                 // the item's index in the classic grid (= its trace row)
-        trace_row = (p.trace && vb < p.trace_rows) ? p.trace + 8 * (long)vb : nullptr;
+        trace_row = (trace_on && p.trace && vb < p.trace_rows) ? p.trace + 8 * (long)vb : nullptr;
         if (trace_row && tid == 0) {
             trace_row[0] = trace_row[1] = __builtin_amdgcn_s_memrealtime();
             trace_row[4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
             trace_row[7] = (long long)blockIdx.x << 16 | (long long)it;
         }
 #ifdef GCCNMF_EXPERIMENTS
-        set_lane_constants(gemm_opaque_tid());
+        set_lane_constants(OPAQUE ? tid : gemm_opaque_tid());
         if (it > 0) set_offsets(lane);
         // every fragment register starts an item defined: a conditional read followed by an unconditional tie would otherwise keep the
         // previous item's values alive across the epilogue (76 registers the epilogue does not have)
@@ -833,6 +942,8 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
 #else
         set_lane_constants(tid);
 #endif
+        gemm_sync_wait(sync, file, col0, tid, sync_it, list, claim_counter, s_claim);   // chained launch: this item's operands come from an earlier stage of the same launch
+        if (trace_row && tid == 0) trace_row[1] = __builtin_amdgcn_s_memrealtime();      // [1] - [0] = time spent waiting for a producer
         // ---- prologue: tile 0 -> buffer 0 (unless the previous item's epilogue already sent it), group 0 of tile 0 into registers
         if (!prefetched) {
 #pragma unroll
@@ -960,6 +1071,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
             __syncthreads();
             if (tid == 0) trace_row[3] = __builtin_amdgcn_s_memrealtime();
         }
+        gemm_sync_signal(sync, e_file, e_col0, e_nw, tid);  // chained launch: this item's output is complete in the XCD's L2
         ++it;
         if (have) __syncthreads();            // s_rowvec, the scratch and s_arrivals are rewritten for the next item
     }
@@ -980,6 +1092,119 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
     }
 }
 
+// The classic launch: one GEMM, workgroup b takes item b >> 3 of list b & 7 (one list: item b).
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW>
+__global__ __launch_bounds__(256, 2) void gccnmf_gemm_dma_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * GemmDmaLds<TM>::SBUF];
+    __shared__ __attribute__((aligned(16))) float s_rowvec[(EPI == EPI_STORE || EPI == EPI_UPDH) ? 2 * 128 * TM : 4];   // lean epilogue row factors
+    __shared__ unsigned s_arrivals;
+    __shared__ int s_ticket[2];
+    const int list = p.lists == 8 ? (int)(blockIdx.x & 7) : 0;
+    const int t = p.lists == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;      // first item: static (the counter starts behind the resident workgroups)
+    GemmSync none = {};
+    gemm_dma_workgroup<A_KC, B_KC, EPI, TAIL, TM, NARROW>(p, smem, s_rowvec, &s_arrivals, s_ticket, list, t, none);
+}
+
+// The chained launch of a KL-NMF iteration (or its first STAGES GEMMs): stage 0 = K1 (R = V / (W.(s*H))), 1 = K2 (H update), 2 = K3
+// (R = V / (W.H)), 3 = K4 (R.H^T with the fused W update).  Workgroup b serves list b & 7; its position b >> 3 falls into one stage's
+// item range [first[s], first[s + 1]).  K1 and K3 are the same tile program on different arguments.
+struct GemmChain {
+    int first[5];                        // per list: stage s serves positions [first[s], first[s + 1]) of an iteration
+    int it0, iterations;                 // iterations of this launch: it0 .. it0 + iterations - 1 (position / first[4] selects one)
+    int trace_it;                        // timeline builds: the iteration whose workgroups write trace rows
+    GemmSync sync[4];
+};
+template <bool TAIL, int STAGES>
+__global__ __launch_bounds__(256, 2) void gccnmf_gemm_chain_kernel(GemmArgs p0, GemmArgs p1, GemmArgs p2, GemmArgs p3, GemmChain ch) {
+    static_assert(STAGES == 2 || STAGES == 4, "");
+    __shared__ __attribute__((aligned(16))) float smem[2 * GemmDmaLds<4>::SBUF];
+    __shared__ __attribute__((aligned(16))) float s_rowvec[2 * 512];
+    __shared__ unsigned s_arrivals;
+    __shared__ int s_ticket[2];
+    const int list = (int)(blockIdx.x & 7);
+    int pos = (int)(blockIdx.x >> 3), it = ch.it0;
+    if (ch.iterations > 1) {
+        const int q = pos / ch.first[4];
+        it += q;
+        pos -= q * ch.first[4];
+    }
+    const bool tr = it == ch.trace_it;
+    if (pos < ch.first[1]) {
+        gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true>(p0, smem, s_rowvec, &s_arrivals, s_ticket, list, pos, ch.sync[0], it, tr);
+    } else if (pos < ch.first[2]) {
+        gemm_dma_workgroup<false, false, EPI_UPDH, false, 4, true>(p1, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[1], ch.sync[1], it, tr);
+    } else if constexpr (STAGES == 4) {
+        if (pos < ch.first[3]) {
+            gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true>(p2, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[2], ch.sync[2], it, tr);
+        } else {
+            gemm_dma_workgroup<true, true, EPI_UPDW, TAIL, 4, false>(p3, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[3], ch.sync[3], it, tr);
+        }
+    }
+}
+
+// The same chain served by RESIDENT workgroups (gridDim.x / 8 per list, two per CU) that pull the items of their XCD's list through a ticket
+// counter until the whole call -- every stage of every iteration -- is done.  The hardware dispatcher hands workgroups to the eight XCDs
+// round-robin and IN ORDER: with items of different lengths (K2's are 110 us, K4's 300 us) and no launch boundary to re-align the XCDs,
+// a free slot on one XCD waits for a slot on another (timelines: 15-35 us gaps between successive workgroups of a slot, 1.6 resident
+// workgroups per CU on average instead of 2).  A ticket per XCD has no such coupling.  The next item is claimed while the current one
+// waits for its operands (gemm_sync_wait), so the claim's round trip is not on the critical path; claiming ONE item ahead cannot deadlock:
+// the lowest unfinished ticket of a list is always either running or the next item of a workgroup whose current (lower) item is finished.
+// The arguments live in device memory (written by gccnmf_chain_args_kernel on the same stream), not in the kernel-argument segment: as
+// kernel arguments they are loop invariants of the ticket loop, and the compiler keeps all four stages' worth of them live through every
+// tile program (483 spilled SGPRs, scratch reloads inside the k loops).  Read through a pointer that is laundered once per item, a tile
+// program holds only its own stage's values, as in the classic kernel.
+struct GemmChainBlock {
+    GemmArgs p[4];
+    GemmChain ch;
+};
+static_assert(sizeof(GemmChainBlock) <= 4096 && sizeof(GemmChainBlock) % 4 == 0, "");
+static __global__ void gccnmf_chain_args_kernel(GemmChainBlock b, unsigned* dst) {
+    const unsigned* src = (const unsigned*)&b;
+    for (int i = threadIdx.x; i < (int)(sizeof(GemmChainBlock) / 4); i += blockDim.x) dst[i] = src[i];
+}
+typedef const __attribute__((address_space(4))) GemmChainBlock* gemm_chain_block_ptr;
+
+template <bool TAIL>
+__global__ __launch_bounds__(256, 2) void gccnmf_gemm_chain_resident_kernel(const GemmChainBlock* block, unsigned* tickets) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * GemmDmaLds<4>::SBUF];
+    __shared__ __attribute__((aligned(16))) float s_rowvec[2 * 512];
+    __shared__ unsigned s_arrivals;
+    __shared__ int s_ticket[2];
+    __shared__ int s_claim[2];
+    const int list = (int)(blockIdx.x & 7);
+    const int wpl = (int)(gridDim.x >> 3);
+    int ticket = (int)(blockIdx.x >> 3);                    // the first item: static (the counter starts behind the resident workgroups)
+    int n = 0;
+    while (true) {
+        unsigned long long laundered = (unsigned long long)block;         // (an integer: a pointer cast there and back would fold away)
+        asm volatile("" : "+s"(laundered));
+        const gemm_chain_block_ptr a = (gemm_chain_block_ptr)laundered;     // constant address space: uniform scalar loads
+        const int per_it = a->ch.first[4];
+        if (ticket >= per_it * a->ch.iterations) break;
+        const int q = ticket / per_it;
+        const int pos = ticket - q * per_it, it = a->ch.it0 + q;
+        const bool tr = it == a->ch.trace_it;
+        unsigned* const tc = tickets + list;
+        int* const sc = s_claim + (n & 1);
+        if (pos < a->ch.first[1]) {
+            gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true, true>(*(const GemmArgs*)&a->p[0], smem, s_rowvec, &s_arrivals, s_ticket, list, pos,
+                                                                    *(const GemmSync*)&a->ch.sync[0], it, tr, tc, sc);
+        } else if (pos < a->ch.first[2]) {
+            gemm_dma_workgroup<false, false, EPI_UPDH, false, 4, true, true>(*(const GemmArgs*)&a->p[1], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[1],
+                                                                       *(const GemmSync*)&a->ch.sync[1], it, tr, tc, sc);
+        } else if (pos < a->ch.first[3]) {
+            gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true, true>(*(const GemmArgs*)&a->p[2], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[2],
+                                                                    *(const GemmSync*)&a->ch.sync[2], it, tr, tc, sc);
+        } else {
+            gemm_dma_workgroup<true, true, EPI_UPDW, TAIL, 4, false, true>(*(const GemmArgs*)&a->p[3], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[3],
+                                                                     *(const GemmSync*)&a->ch.sync[3], it, tr, tc, sc);
+        }
+        __syncthreads();            // every wave is through its epilogue (the staging buffers and s_rowvec are free), the claim is in LDS
+        ticket = wpl + __builtin_amdgcn_readfirstlane(*sc);
+        ++n;
+    }
+}
+
 // ---- host side: the plan of a launch -----------------------------------------------------------------------------------------
 #ifdef GCCNMF_EXPERIMENTS
 unsigned* gccnmf_ticket_block(hipStream_t stream);
@@ -991,7 +1216,7 @@ unsigned* gccnmf_ticket_block(hipStream_t stream);
 //   when the launch shares the chip with another file group's launches (its early finish is used at once), or when the extra items do not
 //   cost the launch another round of workgroup slots (51 files: 128 tiles per XCD fit two rounds of 64, 122 + 7 items do not) | 2 (tests):
 //   every tile as two narrow halves
-static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM) {
+static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM, bool whole_files = false) {
     a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     a.lists = (a.xcd_affine && a.batch >= 8) ? 8 : 1;
@@ -1007,6 +1232,16 @@ static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM) {
         if ((with_rag + slots - 1) / slots > (plain + slots - 1) / slots) a.rag = 0;
     }
     a.wide_n = a.tiles_n - a.rag;
+    a.whole_files = 0;
+    if (whole_files) {
+        if (a.lists != 8 || policy > 1) return -1;
+        a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;      // (no round-count argument: nothing ends at a launch boundary)
+        a.wide_n = a.tiles_n - a.rag;
+        a.whole_files = 1;
+        a.cw = ((a.batch + 7) / 8) * a.tiles_m * a.tiles_n;
+        a.cr = a.split = 0;
+        return a.lists * a.cw;
+    }
     const long wide = (long)a.batch * a.tiles_m * a.wide_n, ragged = (long)a.batch * a.rag * a.tiles_m;
     a.cw = (int)((wide + a.lists - 1) / a.lists);
     a.cr = (int)((ragged + a.lists - 1) / a.lists);

@@ -95,6 +95,7 @@ struct GemmArgs {
     int cw, cr;                // wide tiles / ragged narrow tiles per list (chunks of the file-major lists)
     int split;                 // the last `split` wide tiles of every list run as two narrow (512 x 32) halves
     int rag, wide_n;           // rag = 1: the last column tile of a file is a narrow item; wide_n = tiles_n - rag
+    int whole_files;           // chained launches: list x holds WHOLE files (x, x + 8, ...), each file's items together, its ragged items (rag) behind its wide tiles
     int wpl, prefetch;         // persistent grid: resident workgroups per list; 1 = the next item's first k-tile is requested before the epilogue
     unsigned* tickets;         // persistent grid: [0..7] next-item counters per list, [8] workgroups gone; nullptr = classic grid
     int trace_rows, trace_grid;   // rows of the trace buffer; items of the classic grid (the per-wave probe rows start behind them)

@@ -49,6 +49,10 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {0, 0, 1, 1},                       // 18 persistent
     {1, 0, 1, 1},                       // 19 prefetch
     {1, 0, 1, 1},                       // 20 wide_update_w
+    {0, 0, 9, 0},                       // 21 chain: GEMMs chained in one launch (0 off, 2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call, 9 = 8 on resident workgroups)
+    {0, 0, 1, 1},                       // 22 chain_solo: chained launches with one workgroup per CU (the freedom-from-deadlock test)
+    {1, 0, 1, 0},                       // 23 chain_rag: chained launches on whole-file lists (0: the plain launch's lists, batch a multiple of 8 only)
+    {0, 0, 1, 0},                       // 24 chain_local: ready counters through the XCD's L2 only (1) or agent scope (0)
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
 static std::atomic<int> gccnmf_knobs_ready{0};
@@ -87,7 +91,7 @@ int gccnmf_set_tuning(int key, int value) {
 #ifndef GCCNMF_EXPERIMENTS
     if (k.experiment) return GCCNMF_ERR_ARG;                 // the product build carries none of the code these select
 #endif
-    if (value < k.lo || value > k.hi || (key == 13 && value == 1)) return GCCNMF_ERR_ARG;
+    if (value < k.lo || value > k.hi || (key == 13 && value == 1) || (key == 21 && value != 0 && value != 2 && value != 4 && value < 8)) return GCCNMF_ERR_ARG;
     gccnmf_knob_value[key].store(value, std::memory_order_relaxed);      // takes effect at the next library call (GccNmfCall)
     return GCCNMF_OK;
 }
@@ -834,6 +838,149 @@ static int launch_whdiv_rht(const NmfGeom& g, const float* V, const float* W, co
     return gccnmf_whdiv_rht_launch(a, s);
 }
 
+// ---- chained launches of the iteration (tuning key 21; gemm_dma.h: GemmSync, gccnmf_gemm_chain_kernel) ---------------------------------
+// Counters of one file group, behind everything else in the workspace: c12 [batch][tiles_n] (K1 -> K2, in 32-column blocks), c23
+// [batch][tiles_n] (K2 -> K3), c34 [batch] (K3 -> K4, items), c41 [batch] (K4 -> the next iteration's K1, items), error [1].  Zeroed once per gccnmf_klnmf call; iteration `it` waits for
+// (it + 1) x the per-iteration count, so nothing is reset between launches.
+static long chain_counter_floats(const NmfGeom& g, int batch) { return (long)batch * (2L * gccnmf_ceil_div(g.N, 64) + 2) + 32; }      // ... error [1], 7 unused, tickets [8], XCCs seen per list [8], 8 unused
+static const long chain_args_floats = 1024;          // behind the counters: the argument block of the resident chained grid (GemmChainBlock)
+static long klnmf_workspace_base_floats(const NmfGeom& g, int batch) {
+    long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
+    if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
+    return n + direct_floats(g, batch);
+}
+// Which iterations can be chained: the four GEMMs all on full-height LDS-DMA throughput tiles with one XCD-affine list per XCD, every
+// file's tiles on ONE XCD in every stage (batch a multiple of 8: list x holds the files x, x + 8, ... in all four GEMMs).
+static int chain_stages(const NmfGeom& g, int batch, int flags) {
+    const int want = gccnmf_tune_chain;
+    if (!want || !gccnmf_tune_dma || gccnmf_tune_tile_policy == 2 || gccnmf_tune_tail_split > 1) return 0;
+    if (direct_path(g, batch) || (flags & 3) || batch < 8 || ((batch & 7) && !gccnmf_tune_chain_rag)) return 0;
+    if (g.K <= 256 || g.Fm <= 128 || g.Fm > 512 || (g.Fm & 127) || (g.K & 63) || (g.F % 16) != 1 || !g.tail) return 0;
+    if (gccnmf_tune_tile_policy != 1 && (long)batch * gccnmf_ceil_div(g.N, 64) < 256) return 0;      // (the small-batch tile's territory)
+    if (!can_fuse_w_update(g, batch)) return 0;
+    return want;
+}
+
+static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, float* W, float* H, float* R, float* colsumW, float* hscale,
+                              float alpha, float eps, int batch, int flags, unsigned* counters, int it0, int iterations, bool resident, hipStream_t s) {
+    GemmArgs a[4] = {};
+    const int concurrent = (flags & 4) ? 1 : 0;
+    for (int i = 0; i < 4; ++i) {
+        a[i].batch = batch; a[i].xcd_affine = 1; a[i].concurrent = concurrent;
+        a[i].ablate = gccnmf_tune_ablate; a[i].exact_div = gccnmf_tune_exact_div;
+    }
+    for (int i = 0; i < 3; i += 2) {             // K1 (pending row scale of H on the B fragments) and K3: R = V / (W.H)  (launch_wh_div)
+        a[i].A = W; a[i].sA = g.sW; a[i].lda = g.Kp; a[i].a_clamp = g.Fp - 1;
+        a[i].B = H; a[i].sB = g.sH; a[i].ldb = g.ld; a[i].b_clamp = g.Np - 4;
+        a[i].M = g.Fm; a[i].N = g.N; a[i].Kd = g.K;
+        a[i].tail_row = g.F - 1;
+        a[i].C = R; a[i].sC = g.sV; a[i].ldc = g.ld;
+        a[i].E0 = V; a[i].sE0 = g.sV;
+    }
+    a[0].bscale = hscale; a[0].s_bscale = g.Kp;
+    // K2: H = (s*H) * (W^T.R) / (colsum W + alpha + eps)  (launch_update_h)
+    a[1].A = W; a[1].sA = g.sW; a[1].lda = g.Kp; a[1].a_clamp = g.Kp - 4;
+    a[1].B = R; a[1].sB = g.sV; a[1].ldb = g.ld; a[1].b_clamp = g.Np - 4;
+    a[1].M = g.K; a[1].N = g.N; a[1].Kd = g.F - 1;
+    a[1].ktailA = W + (long)(g.F - 1) * g.Kp; a[1].s_ktailA = g.sW;
+    a[1].ktailB = R + (long)(g.F - 1) * g.ld; a[1].s_ktailB = g.sV;
+    a[1].C = H; a[1].sC = g.sH; a[1].ldc = g.ld;
+    a[1].E1 = hscale; a[1].sE1 = g.Kp;
+    a[1].E2 = colsumW; a[1].sE2 = g.Kp;
+    a[1].alpha = alpha; a[1].eps = eps;
+    // K4: W = normalise(W * (R.H^T) / rowsum H), column sums, norms  (launch_rht_update_w)
+    a[3].A = R; a[3].sA = g.sV; a[3].lda = g.ld; a[3].a_clamp = g.Fp - 1;
+    a[3].B = H; a[3].sB = g.sH; a[3].ldb = g.ld; a[3].b_clamp = g.Kp - 1;
+    a[3].M = g.Fm; a[3].N = g.K; a[3].Kd = g.N;
+    a[3].tail_row = g.F - 1;
+    a[3].C = W; a[3].sC = g.sW; a[3].ldc = g.Kp;
+    a[3].out_colsum = colsumW; a[3].out_norm = hscale; a[3].s_out = g.Kp;
+    GemmChain ch = {};
+    for (int i = 0; i < 4; ++i) {
+        int len = 0;
+        if (i < stages) {
+            // whole-file lists (key 23, default): any batch size, K4 never waits for a ragged K3 item at the end of a list
+            const int grid = gemm_dma_plan(a[i], i != 3, 4, gccnmf_tune_chain_rag != 0);
+            if (grid < 8 || a[i].lists != 8 || a[i].split) return GCCNMF_ERR_ARG;
+            len = grid / 8;
+        }
+        ch.first[i + 1] = ch.first[i] + len;
+    }
+    const int tn = gccnmf_ceil_div(g.N, 64);
+    unsigned* c12 = counters;
+    unsigned* c23 = c12 + (long)batch * tn;
+    unsigned* c34 = c23 + (long)batch * tn;
+    unsigned* c41 = c34 + batch;
+    unsigned* err = c41 + batch;
+    for (int i = 0; i < 4; ++i) {
+        ch.sync[i].error = err;
+        ch.sync[i].last_tile = tn - 1;
+    }
+    // K1 -> K2: column tile j of a file is ready when its 32-column blocks (2; the ragged last tile as ONE narrow item: 1) are stored
+    ch.sync[0].sig_cnt = c12; ch.sync[0].sig_stride = tn; ch.sync[0].sig_per_tile = 1;
+    ch.sync[1].wait_cnt = c12; ch.sync[1].wait_stride = tn; ch.sync[1].wait_per_tile = 1;
+    ch.sync[1].wait_need = 2u; ch.sync[1].wait_need_last = a[0].rag ? 1u : 2u;
+    if (stages == 4) {
+        // K2 -> K3: both atom tiles (tiles_m of K2) of column tile j;  K3 -> K4: every item of the file
+        ch.sync[1].sig_cnt = c23; ch.sync[1].sig_stride = tn; ch.sync[1].sig_per_tile = 1;
+        ch.sync[2].wait_cnt = c23; ch.sync[2].wait_stride = tn; ch.sync[2].wait_per_tile = 1;
+        ch.sync[2].wait_need = 2u * a[1].tiles_m; ch.sync[2].wait_need_last = (a[1].rag ? 1u : 2u) * a[1].tiles_m;
+        ch.sync[2].sig_cnt = c34; ch.sync[2].sig_stride = 1; ch.sync[2].sig_per_tile = 0;
+        ch.sync[3].wait_cnt = c34; ch.sync[3].wait_stride = 1; ch.sync[3].wait_per_tile = 0;
+        ch.sync[3].wait_need = ch.sync[3].wait_need_last = (unsigned)(a[2].tiles_m * a[2].tiles_n);
+        if (iterations > 1 || resident) {
+            // K4 -> the next iteration's K1: every atom tile of the file (W, its column sums and the pending row scale are complete; R is free)
+            ch.sync[3].sig_cnt = c41; ch.sync[3].sig_stride = 1; ch.sync[3].sig_per_tile = 0;
+            ch.sync[0].wait_cnt = c41; ch.sync[0].wait_stride = 1; ch.sync[0].wait_per_tile = 0; ch.sync[0].wait_lag = 1;
+            ch.sync[0].wait_need = ch.sync[0].wait_need_last = (unsigned)(a[3].tiles_m * a[3].tiles_n);
+        }
+    }
+    if ((iterations > 1 || resident) && stages != 4) return GCCNMF_ERR_ARG;
+    ch.it0 = it0; ch.iterations = iterations;
+    ch.trace_it = it0 + iterations - 1;
+    if ((long)8 * ch.first[4] * iterations > (1L << 30)) return GCCNMF_ERR_ARG;
+    for (int i = 0; i < stages; ++i) {           // timeline builds (gccnmf_debug_set_trace): stage i's item t of list x -> row 8 * (first[i] + t) + x
+        a[i].trace = gccnmf_trace_buf ? gccnmf_trace_buf + 8L * 8 * ch.first[i] : nullptr;
+        a[i].trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks - 8 * ch.first[i] : 0;
+        if (a[i].trace_rows <= 0) a[i].trace = nullptr;
+    }
+    const int grid = 8 * ch.first[4] * iterations;
+    const unsigned pad = gccnmf_tune_chain_solo ? 16384u : 0u;         // static 78 KB + 16 KB: one workgroup per CU
+    if (resident) {
+        if (stages != 4 || !g.tail) return GCCNMF_ERR_ARG;
+        // two resident workgroups per CU (one with key 22), never more than there are items in a list
+        int wpl = gccnmf_tune_chain_solo ? 32 : 64;
+        if (wpl > ch.first[4] * iterations) wpl = ch.first[4] * iterations;
+        GemmChainBlock blk;
+        for (int i = 0; i < 4; ++i) blk.p[i] = a[i];
+        blk.ch = ch;
+        unsigned* dst = err + 32;                                     // (16-byte aligned: the workspace is, and every region before is a multiple of 4 floats... checked below)
+        if (((size_t)dst & 15) != 0) dst += (4 - (((size_t)dst >> 2) & 3)) & 3;
+        hipLaunchKernelGGL(gccnmf_chain_args_kernel, dim3(1), dim3(256), 0, s, blk, dst);
+        GCCNMF_CHECK_LAUNCH();
+        hipLaunchKernelGGL((gccnmf_gemm_chain_resident_kernel<true>), dim3(8 * wpl), dim3(256), pad, s, (const GemmChainBlock*)dst, err + 8);
+    } else if (stages == 2) {
+        if (g.tail) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 2>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
+        else return GCCNMF_ERR_ARG;
+    } else {
+        if (g.tail) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 4>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
+        else return GCCNMF_ERR_ARG;
+    }
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// a consumer gave up waiting (GEMM_SYNC_TIMEOUT), or the workgroups of a list were NOT all on one XCD (the data hand-over through that XCD's
+// L2 is then not guaranteed): the factors cannot be trusted -- make them NaN so that nothing downstream looks plausible
+__global__ void nmf_chain_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ W, float* __restrict__ H, long nW, long nH) {
+    bool bad = err[0] != 0u;
+    for (int l = 0; l < 8; ++l) bad = bad || __popc(err[16 + l]) > 1;
+    if (!bad) return;
+    const float nan = __int_as_float(0x7fc00000);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nW; i += 256L * gridDim.x) W[i] = nan;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nH; i += 256L * gridDim.x) H[i] = nan;
+}
+
 extern "C" {
 
 // R [batch][Fp][Np] | U [batch][Fp][Kp] | colsumW, rowsumH, hscale [batch][Kp] each | (batch == 1) the split-K partials:
@@ -843,9 +990,8 @@ long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     GCCNMF_ENTER();
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
-    long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
-    if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
-    return n + direct_floats(g, batch);                       // Wt | Ht | Rt of the direct path (a handful of files at most)
+    // R | U | colsumW | rowsumH | hscale | split-K scratch (one file) | Wt | Ht | Rt of the direct path (a handful of files at most) | chain counters
+    return klnmf_workspace_base_floats(g, batch) + chain_counter_floats(g, batch) + chain_args_floats;
 }
 
 // One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
@@ -969,9 +1115,25 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     NmfGeom g = make_geom(F, N, K);
     int rc;
     if ((rc = klnmf_stage(0, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
-    for (int it = 0; it < iterations; ++it)
-        for (int stage = 1; stage <= 5; ++stage)
-            if ((rc = klnmf_stage(stage, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
+    const int chained = chain_stages(g, batch, flags);          // 0 | 2: K1 | K2 in one launch | 4: the whole iteration | 8: the whole call
+    unsigned* counters = (unsigned*)(workspace + klnmf_workspace_base_floats(g, batch));
+    if (chained && iterations > 0 && hipMemsetAsync(counters, 0, sizeof(unsigned) * chain_counter_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    float* R = workspace;
+    float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;
+    float* hscale = colsumW + 2L * batch * g.Kp;
+    if (chained >= 8 && iterations > 0) {
+        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, 0, iterations, chained == 9, s))) return rc;
+    } else {
+        for (int it = 0; it < iterations; ++it) {
+            if (chained && (rc = launch_klnmf_chain(chained, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, it, 1, false, s))) return rc;
+            for (int stage = chained + 1; stage <= 5; ++stage)
+                if ((rc = klnmf_stage(stage, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
+        }
+    }
+    if (chained && iterations > 0) {
+        hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
+        GCCNMF_CHECK_LAUNCH();
+    }
     return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
 }
 

@@ -758,3 +758,109 @@ def test_klnmf_dma_staging_vs_oracle(hip, dma_throughput_tile, F, N, K, iters, a
     W, H = performKLNMF(V, K, iters, alpha)
     Wr, Hr = O.performKLNMF(V, K, iters, alpha)
     assert rel(W, Wr) < 1e-4 and rel(H, Hr) < 1e-4, (rel(W, Wr), rel(H, Hr))
+
+
+# ------------------------------------------------------------------------------------------------
+# chained launches of the iteration (tuning key 21; csrc/gemm_dma.h: GemmSync)
+# ------------------------------------------------------------------------------------------------
+def _klnmf_run(lib, V, W0, H0, F, N, K, B, iters, flags=0):
+    from gcc_nmf_amd.engine import Geometry, padded
+    g = Geometry(F, N // 2, K)
+    dV = padded(V, (B, g.Fp, g.Np), 'cuda')
+    dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
+    dH = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
+    ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
+    assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, iters, 0.0, 1e-16, flags, stream()) == 0
+    torch.cuda.synchronize()
+    return dW, dH
+
+
+@pytest.mark.parametrize('B,T,K,iters', [(16, 622, 1024, 6), (64, 622, 1024, 3), (24, 330, 512, 5), (8, 1300, 320, 4), (26, 622, 1024, 4), (13, 622, 512, 3),
+                                         (77, 622, 320, 2)])
+def test_chained_iteration_is_bitwise_the_four_launches(hip, B, T, K, iters):
+    """Tuning key 21: K1 | K2 (2), the whole iteration K1 | K2 | K3 | K4 (4), or EVERY iteration of the call (8) as ONE launch whose
+    consumers wait on per-tile / per-file ready counters in the XCD's L2 instead of on kernel boundaries.  Same tile programs, same k order per element: W and H after several
+    iterations are bit for bit those of the four-launch form -- and finite (a consumer that gave up waiting poisons them with NaN)."""
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    lib = hip.lib()
+    F, N = 513, 2 * T
+    rng = np.random.RandomState(B + K)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    res = {}
+    try:
+        for chain in (0, 2, 4, 8, 9):
+            assert lib.gccnmf_set_tuning(21, chain) == 0
+            res[chain] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+            if chain:
+                res[(chain, 'again')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        # the ready counters through the XCD's own L2 (key 24), and -- batch a multiple of 8 -- on the plain launch's lists (key 23 = 0)
+        assert lib.gccnmf_set_tuning(24, 1) == 0
+        res[(8, 'local')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        assert lib.gccnmf_set_tuning(24, 0) == 0
+        if B % 8 == 0:
+            assert lib.gccnmf_set_tuning(23, 0) == 0 and lib.gccnmf_set_tuning(21, 8) == 0
+            res[(8, 'plain lists')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+    finally:
+        lib.gccnmf_set_tuning(21, 0)
+        lib.gccnmf_set_tuning(23, 1)
+        lib.gccnmf_set_tuning(24, 0)
+    W, H = res[0]
+    assert torch.isfinite(W).all() and torch.isfinite(H).all()
+    for key, (Wc, Hc) in res.items():
+        assert torch.equal(Wc, W) and torch.equal(Hc, H), key
+
+
+def test_chained_iteration_in_two_file_groups_on_two_streams(hip):
+    """The engine's two file groups (two streams, GCCNMF_FLAG_GROUPS) with chained launches in each: bitwise the unchained result."""
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    lib = hip.lib()
+    xs = synthetic_batch(700, 32)
+    outs = []
+    try:
+        for chain in (0, 4, 8, 9):
+            assert lib.gccnmf_set_tuning(21, chain) == 0
+            e = GCCNMFEngine(160000, dictionarySize=1024, numIterations=6, batch=32)
+            assert e.nmf_groups == 2
+            e.upload(xs)
+            e.stft()
+            e.klnmf()
+            torch.cuda.synchronize()
+            outs.append((e.W.clone(), e.H.clone()))
+    finally:
+        lib.gccnmf_set_tuning(21, 0)
+    assert torch.isfinite(outs[0][0]).all()
+    for W, H in outs[1:]:
+        assert torch.equal(outs[0][0], W) and torch.equal(outs[0][1], H)
+
+
+def test_chained_launch_completes_with_one_workgroup_per_cu(hip):
+    """Freedom from deadlock rests on the in-order dispatcher: a consumer is only ever dispatched after every producer it waits for.  The
+    sharpest case is the least residency: key 22 (experiment build) makes a chained launch reserve so much LDS that ONE workgroup fits a
+    CU -- 256 resident workgroups, each possibly spinning.  The run completes, is finite (no consumer timed out) and bitwise the same."""
+    lib = hip.lib()
+    if lib.gccnmf_set_tuning(22, 1) != 0:
+        pytest.skip('key 22 (chained launches with one workgroup per CU) exists in experiment builds only: make EXPERIMENTS=1')
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    B, T, K, iters = 32, 622, 1024, 4
+    F, N = 513, 2 * T
+    rng = np.random.RandomState(5)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    try:
+        assert lib.gccnmf_set_tuning(21, 4) == 0
+        Ws, Hs = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        assert lib.gccnmf_set_tuning(21, 8) == 0
+        Wc, Hc = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)       # the whole call as one launch, still one workgroup per CU
+        assert lib.gccnmf_set_tuning(21, 9) == 0
+        Wr, Hr = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)       # ... and on 256 resident workgroups pulling tickets
+        assert torch.equal(Wr, Wc) and torch.equal(Hr, Hc)
+        assert lib.gccnmf_set_tuning(22, 0) == 0
+        assert lib.gccnmf_set_tuning(21, 0) == 0
+        W, H = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+    finally:
+        lib.gccnmf_set_tuning(22, 0)
+        lib.gccnmf_set_tuning(21, 0)
+    assert torch.isfinite(W).all() and torch.isfinite(Ws).all()
+    assert torch.equal(Ws, W) and torch.equal(Hs, H) and torch.equal(Wc, W) and torch.equal(Hc, H)

@@ -58,11 +58,12 @@ def test_pitches_and_workspace_sizes():
     assert lib.gccnmf_pitches(1, 622, 128, *[ctypes.byref(x) for x in v]) == 1           # GCCNMF_ERR_ARG
     base = 528 * 1280 + 528 * 1024 + 3 * 1024                      # R, U, three K-vectors per file
     direct = 1024 * 528 + 1280 * 1024 + 1280 * 528                 # Wt, Ht, Rt: the transposed copies of the direct path, per file
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * (base + direct)
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 64) == 64 * base                           # (a handful of files at most)
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + direct      # + the split-K partials of one file alone
+    chain = lambda batch: batch * (2 * 20 + 2) + 32 + 1024         # (+ the argument block of the resident chained grid) ready counters of the chained launches (K1 -> K2, K2 -> K3 per column tile; K3 -> K4, K4 -> K1 per file) + error flag
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * (base + direct) + chain(2)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 64) == 64 * base + chain(64)               # (a handful of files at most)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + direct + chain(1)      # + the split-K partials of one file alone
     assert lib.gccnmf_klnmf_workspace_floats(513, 0, 1024, 1) == -1
-    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 128, 64) == 64 * (528 * 1280 + 528 * 128 + 3 * 128)     # (the fused short-dictionary launches need no scratch)
+    assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 128, 64) == 64 * (528 * 1280 + 528 * 128 + 3 * 128) + chain(64)     # (the fused short-dictionary launches need no scratch)
     # argument checking happens before any HIP call, so it is testable without a GPU
     assert lib.gccnmf_klnmf(0, 0, 0, 0, 513, 1244, 1024, 1, 1, 0.0, 1e-16, 0, 0) == 1
     assert lib.gccnmf_stft_stereo(0, 0, 0, 1000, 256, 1, 1, 0, 0, 0, 0, 0, 0) == 1
