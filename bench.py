@@ -58,7 +58,7 @@ def parse():
     return p.parse_args()
 
 
-def live_traffic(a, timeout_s=150):
+def live_traffic(a, timeout_s=150, chained=False):
     """HBM bytes per launch of the K1 / K3 kernel, measured NOW: two child runs of this file (10 KL-NMF iterations of the same batch on
     one stream, nothing else) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, the
     counter units and the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md's HBM section (KB = 1024 B; FETCH_SIZE reports half
@@ -78,7 +78,7 @@ def live_traffic(a, timeout_s=150):
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='gccnmf_pmc_', dir='/tmp')
         cmd = [roc, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pass', '--',
-               sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '1', '--warmup', '0', '--iterations', '10',
+               sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '1', '--warmup', '0', '--iterations', str(a.iterations if chained else 10),
                '--files', str(a.files), '--dictionary-size', str(a.dictionary_size), '--hop', str(a.hop), '--seconds', str(a.seconds),
                '--nmf-groups', '1', '--skip-extras', '--skip-roofline', '--skip-config-lines', '--skip-cpu-baseline', '--no-live-traffic']
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
@@ -100,7 +100,9 @@ def live_traffic(a, timeout_s=150):
             for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
                 for r in csv.DictReader(open(f)):
                     # K1 and K3 are the same instantiation: A stored [row][k], B not, EPI_DIV (= 1)
-                    if r['Counter_Name'] == counter and r['Kernel_Name'].startswith('void gccnmf_gemm_dma_kernel<true, false, 1,'):
+                    # the chained launch: ONE kernel holds every GEMM of every iteration of the call
+                    want = 'void gccnmf_gemm_chain_kernel<' if chained else 'void gccnmf_gemm_dma_kernel<true, false, 1,'
+                    if r['Counter_Name'] == counter and r['Kernel_Name'].startswith(want):
                         vals.append(float(r['Counter_Value']))
             if not vals:
                 return None, 'no %s rows for the K1 / K3 kernel' % counter
@@ -114,8 +116,10 @@ def live_traffic(a, timeout_s=150):
     return ({'hbm_bytes_per_launch': (2.0 * fetch_kb + write_kb) * 1024.0, 'fetch_size_kb_raw': fetch_kb, 'write_size_kb': write_kb,
              'launches': n, 'seconds': time.perf_counter() - t0},
             'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of bench.py --iterations 10 '
-            '--nmf-groups 1, mean over %d launches of gccnmf_gemm_dma_kernel<true,false,1,...> = K1 + K3); FETCH_SIZE doubled (gfx950 reports '
-            'half of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section), KB = 1024 B' % n)
+            '--nmf-groups 1, mean over %d launches of %s); FETCH_SIZE doubled (gfx950 reports '
+            'half of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section), KB = 1024 B'
+            % (n, 'gccnmf_gemm_chain_kernel<true,4> = the whole KL-NMF call, %d iterations x (K1 | K2 | K3 | K4)' % a.iterations if chained
+               else 'gccnmf_gemm_dma_kernel<true,false,1,...> = K1 + K3'))
 
 
 def kernel_timings(e, iterations=10, launches=20):
@@ -167,7 +171,22 @@ def kernel_timings(e, iterations=10, launches=20):
         stage(3)
     e3.record()
     torch.cuda.synchronize()
-    return (min(t_long) - min(t_short)) / (2 * iterations), e2.elapsed_time(e3) / launches
+    call_ms = None
+    if lib.gccnmf_klnmf_plan(g.F, g.N, g.K, e.batch, e.klnmf_flags) & 8:
+        # the chained launch: the whole call (e.iters iterations) is ONE kernel -- time it as the product runs it (the call's few small kernels --
+        # zeroing R and the counters, the prepare / final H-scale launches, ~50 us together -- ride inside the event pair)
+        ts = []
+        for _ in range(3):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            e.W.copy_(e.W0.unsqueeze(0).expand_as(e.W))
+            e.H.copy_(e.H0.unsqueeze(0).expand_as(e.H))
+            ev[0].record()
+            loop(e.iters)
+            ev[1].record()
+            torch.cuda.synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]))
+        call_ms = min(ts)
+    return (min(t_long) - min(t_short)) / (2 * iterations), e2.elapsed_time(e3) / launches, call_ms
 
 
 def shared_dictionary_mode(a, e, xs, world, rank, local_rank, barrier, ranks_seen=1, backend='nccl'):
@@ -368,7 +387,7 @@ def config_lines(a, e, xs, sr, n, local_rank):
         eng.upload(xs)
         dt = timed_runs(eng, steps)
         g = eng.g
-        iter_ms, k3_ms = kernel_timings(eng, iterations=10, launches=10)
+        iter_ms, k3_ms, _call_ms = kernel_timings(eng, iterations=10, launches=10)
         gemm_flop = 2.0 * g.F * g.K * g.N * B
         plan = int(eng.lib.gccnmf_klnmf_plan(g.F, g.N, g.K, eng.batch, eng.klnmf_flags))
         slabs = bool(plan & 4)
@@ -662,7 +681,7 @@ def main():
     if rank == 0 and not a.skip_roofline:
         traffic_file = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else None
-        iter_ms, k3_ms = kernel_timings(e)
+        iter_ms, k3_ms, chain_call_ms = kernel_timings(e)
         gemm_flop = 2.0 * g.F * g.K * g.N * B                                # algorithmic: F=513, N=2T, not the padded tile grid
         # short dictionaries: the library may run K3 + K4a as ONE launch of 64-bin slabs (gccnmf_klnmf_plan bit 2) -- then that launch is
         # the dominant kernel, and it holds two GEMMs
@@ -677,7 +696,23 @@ def main():
                            'launch': 'one launch over all %d files on one stream, %d back to back (the timed steps run KL-NMF as %d file '
                                      'group(s) on separate streams, whose launches overlap in time; rocprofv3 averages of this launch: '
                                      'python bench.py --nmf-groups 1)' % (B, 20, e.nmf_groups)}
-        if pmc and pmc.get('files_per_gpu') == B and pmc.get('dictionary_size') == K and a.seconds == 10.0 and a.hop == 256:
+        chained = chain_call_ms is not None
+        if chained:
+            # The dominant kernel of the product path is now the chained launch itself: every GEMM of every iteration of the call in one kernel
+            # (tuning key 21).  achieved = the call's algorithmic flop (4 GEMMs x iterations) / the launch's duration; the K3 launch ALONE (the
+            # dominant kernel of rounds 1-5, still what a forced plain form runs) stays in `k3_alone`.
+            out['roofline'].update({
+                'kernel': 'gccnmf_gemm_chain_kernel<TAIL,4> (the whole KL-NMF call: %d iterations x (K1 | K2 | K3 | K4 with the fused W update), tiles handed '
+                          'over through ready counters in the XCD\'s L2)' % iters,
+                'achieved': 4 * gemm_flop * iters / (chain_call_ms * 1e-3) / 1e12, 'flop_per_launch': 4 * gemm_flop * iters, 'avg_launch_ms': float(chain_call_ms),
+                'launch': 'ONE launch per gccnmf_klnmf call over all %d files on one stream, best of 3 (HIP events on the launch stream)' % B,
+                'k3_alone': {'kernel': kernel_name, 'achieved': achieved, 'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'flop_per_launch': flop_per_launch,
+                             'avg_launch_ms': float(k3_ms), 'launch': '20 plain launches of K3 back to back'}})
+            out['roofline']['frac'] = out['roofline']['achieved'] / F32_MFMA_PEAK_TFLOPS
+            # unique operand bytes of one iteration: K1 / K3 read V, W, H and write R; K2 reads W, R, H and writes H; K4 reads R, H, W and writes W
+            per_file = 4.0 * (2 * (g.F * g.N * 2 + g.F * K + K * g.N) + (g.F * K + g.F * g.N + 2 * K * g.N) + (g.F * g.N + K * g.N + 2 * g.F * K))
+            out['roofline']['traffic_algorithmic_unique_bytes'] = per_file * B * iters
+        if not chained and pmc and pmc.get('files_per_gpu') == B and pmc.get('dictionary_size') == K and a.seconds == 10.0 and a.hop == 256:
             # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (profiles/README.md), gfx950-corrected
             out['roofline']['traffic'] = pmc['k1_hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = pmc['source']
@@ -685,7 +720,9 @@ def main():
         # one KL-NMF iteration = the four dependent GEMM launches of the library's own loop (W update fused into the R.H^T launch), whole
         # batch on ONE stream: difference of two gccnmf_klnmf calls of different lengths.  The kernel trace shows the launches back to
         # back (start of n+1 = end of n, profiles/r05o_launch_gaps.json), so this is the sum of the four kernel durations; the timed
-        # steps run two file groups on two streams and overlap the tail of one group's launch with the head of the other's.
+        # steps run two file groups on two streams and overlap the tail of one group's launch with the head of the other's.  Round 6: where the
+        # library chains the call (gccnmf_klnmf_plan bit 3) there are no launches per iteration any more -- this is the steady-state cost of one
+        # iteration inside the call's single launch, and the timed steps run ONE file group.
         out['nmf_iteration_one_stream'] = {'ms': float(iter_ms), 'tflops': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12,
                                            'frac_of_peak': 4 * gemm_flop / (iter_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
 
@@ -807,7 +844,7 @@ def main():
     if rank == 0 and world == 1 and 'roofline' in out and not slabs and not a.skip_extras and not a.no_live_traffic:
         # LAST, with every other number already in `out` and this process idle on the device: the kernel's HBM traffic from the counters
         torch.cuda.synchronize()
-        rec, note = live_traffic(a)
+        rec, note = live_traffic(a, chained='k3_alone' in out['roofline'])
         if rec:
             out['roofline']['traffic_recorded'] = out['roofline']['traffic']
             out['roofline']['traffic'] = rec['hbm_bytes_per_launch']

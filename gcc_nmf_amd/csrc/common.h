@@ -51,8 +51,9 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //   12   direct_batch      4     1..8    largest batch on the direct path
 //   16   fused_k12         1     0..2    K <= 128: K1 + K2 as one launch of column tiles (0 never, 1 by cost model, 2 always)
 //   17   fused_k34         1     0..2    K <= 128: K3 + K4a as one launch of bin slabs
-//   21   chain             0  0,2,4,8,9  batch scale, K > 256: the first 2 / all 4 GEMMs of an iteration, or (8) every iteration of the call, as ONE chained launch (gemm_dma.h: GemmSync);
-//                                        9 = 8 served by resident workgroups through per-XCD tickets
+//   21   chain             1   0,1,2,4,8 batch scale, K > 256: 1 = the whole gccnmf_klnmf call as ONE chained launch (gemm_dma.h: GemmSync) where it wins (>= 3 files per
+//                                        XCD, balanced whole-file lists, no other file group beside it); 0 = never; forced forms: 2 = K1 | K2, 4 = the four GEMMs of
+//                                        an iteration, 8 = every iteration of the call
 //   23   chain_rag         1     0..1    chained launches on whole-file lists: list x = files x, x + 8, ..., a file's ragged tiles behind its wide ones; any batch >= 13
 //                                        (0: the plain launch's lists -- equal eighths, short items last -- batch a multiple of 8 only)
 //   24   chain_local       0     0..1    1 = the chained launches' ready counters live in the XCD's own L2 (scope-less atomic add, L1-bypassing polls)

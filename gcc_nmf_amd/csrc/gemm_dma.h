@@ -506,34 +506,23 @@ __device__ __forceinline__ unsigned gemm_sync_peek(const unsigned* counter, int 
     return v;
 }
 // it: the iteration this workgroup belongs to, counted from the zeroing of the counters.
-// ticket_counter != nullptr (resident chained grid): thread 0 also CLAIMS the workgroup's next item here -- a returning agent-scope atomic add
-// issued together with the first poll, so that its round trip (~3 us across eight XCDs) costs nothing extra -- and leaves it in *s_next.
-__device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int col0, int tid, int it, int list, unsigned* ticket_counter = nullptr,
-                                               int* s_next = nullptr) {
+__device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int col0, int tid, int it, int list) {
     if (y.xcc_seen && tid == 0) {        // the hand-over relies on a list's workgroups sharing ONE XCD's L2: recorded here (no return, no wait), judged after the call
         const unsigned bit = 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);      // HW_REG_XCC_ID
         asm volatile("global_atomic_or %0, %1, off sc1" : : "v"(y.xcc_seen + list), "v"(bit) : "memory");
     }
     if (y.wait_cnt) {                    // (kernel argument: wave-uniform)
         if (tid == 0) {
-            unsigned claimed = 0;
-            if (ticket_counter) asm volatile("global_atomic_add %0, %1, %2, off sc0 sc1" : "=&v"(claimed) : "v"(ticket_counter), "v"(1u) : "memory");
             const int tile = col0 >> 6;
             const unsigned* c = y.wait_cnt + (long)file * y.wait_stride + (y.wait_per_tile ? tile : 0);
             const unsigned need = ((y.wait_per_tile && tile == y.last_tile) ? y.wait_need_last : y.wait_need) * (unsigned)(it + 1 - y.wait_lag);
             const long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned seen = gemm_sync_peek(c, y.local);                // (its s_waitcnt vmcnt(0) also covers the claim)
-            if (ticket_counter) {
-                gemm_tie(claimed);
-                *s_next = (int)claimed;
-            }
-            while (seen < need) {
+            while (gemm_sync_peek(c, y.local) < need) {
                 __builtin_amdgcn_s_sleep(16);
                 if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GEMM_SYNC_TIMEOUT) {
                     *y.error = 1u;
                     break;
                 }
-                seen = gemm_sync_peek(c, y.local);
             }
         }
         __syncthreads();
@@ -562,12 +551,10 @@ struct GemmDmaLds {
 };
 
 // One workgroup of the throughput tile: items t, (persistent grid: further tickets) of list `list`.
-// OPAQUE: the caller runs this inside a loop of its own (resident chained grid): every per-lane value is derived from an opaque copy of the
-// thread index, so that none of them is a loop invariant of THAT loop (they would be kept live -- spilled -- across all four tile programs)
-template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW, bool OPAQUE = false>
+template <bool A_KC, bool B_KC, int EPI, bool TAIL, int TM, bool NARROW>
 __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* const smem, float* const s_rowvec, unsigned* const s_arrivals_p,
                                                    int* const s_ticket, const int list, int t, const GemmSync& sync, const int sync_it = 0,
-                                                   const bool trace_on = true, unsigned* const claim_counter = nullptr, int* const s_claim = nullptr) {
+                                                   const bool trace_on = true) {
     static_assert(TM == 4 || TM == 2, "");
     static_assert(TM == 4 || EPI != EPI_UPDW, "the fused W update owns all rows of its atoms: full-height tiles only");
     static_assert(!NARROW || (EPI != EPI_UPDW && TM == 4), "narrow items: full-height tiles with an element-wise epilogue");
@@ -581,7 +568,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
 
     // Per-lane values are RE-DERIVED per item from an opaque copy of the thread index (gemm_opaque_tid): as loop invariants of the item
     // loop they would stay live across the epilogue, whose 128 accumulators + two tile pairs of inputs leave no registers for them.
-    int tid = OPAQUE ? gemm_opaque_tid() : (int)threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform in an SGPR: LDS-DMA bases derive from it
     const int wm = wave, wn = 0;
     int l31 = lane & 31, hh = lane >> 5;
@@ -932,7 +919,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
             trace_row[7] = (long long)blockIdx.x << 16 | (long long)it;
         }
 #ifdef GCCNMF_EXPERIMENTS
-        set_lane_constants(OPAQUE ? tid : gemm_opaque_tid());
+        set_lane_constants(gemm_opaque_tid());
         if (it > 0) set_offsets(lane);
         // every fragment register starts an item defined: a conditional read followed by an unconditional tie would otherwise keep the
         // previous item's values alive across the epilogue (76 registers the epilogue does not have)
@@ -942,7 +929,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
 #else
         set_lane_constants(tid);
 #endif
-        gemm_sync_wait(sync, file, col0, tid, sync_it, list, claim_counter, s_claim);   // chained launch: this item's operands come from an earlier stage of the same launch
+        gemm_sync_wait(sync, file, col0, tid, sync_it, list);   // chained launch: this item's operands come from an earlier stage of the same launch
         if (trace_row && tid == 0) trace_row[1] = __builtin_amdgcn_s_memrealtime();      // [1] - [0] = time spent waiting for a producer
         // ---- prologue: tile 0 -> buffer 0 (unless the previous item's epilogue already sent it), group 0 of tile 0 into registers
         if (!prefetched) {
@@ -1114,7 +1101,8 @@ struct GemmChain {
     int trace_it;                        // timeline builds: the iteration whose workgroups write trace rows
     GemmSync sync[4];
 };
-template <bool TAIL, int STAGES>
+// TM1: height of K2's tiles in 128-row units -- 2 for dictionaries of at most 256 atoms (a full tile would leave two of its four waves idle)
+template <bool TAIL, int STAGES, int TM1>
 __global__ __launch_bounds__(256, 2) void gccnmf_gemm_chain_kernel(GemmArgs p0, GemmArgs p1, GemmArgs p2, GemmArgs p3, GemmChain ch) {
     static_assert(STAGES == 2 || STAGES == 4, "");
     __shared__ __attribute__((aligned(16))) float smem[2 * GemmDmaLds<4>::SBUF];
@@ -1132,76 +1120,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_gemm_chain_kernel(GemmArgs p0, 
     if (pos < ch.first[1]) {
         gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true>(p0, smem, s_rowvec, &s_arrivals, s_ticket, list, pos, ch.sync[0], it, tr);
     } else if (pos < ch.first[2]) {
-        gemm_dma_workgroup<false, false, EPI_UPDH, false, 4, true>(p1, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[1], ch.sync[1], it, tr);
+        gemm_dma_workgroup<false, false, EPI_UPDH, false, TM1, TM1 == 4>(p1, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[1], ch.sync[1], it, tr);
     } else if constexpr (STAGES == 4) {
         if (pos < ch.first[3]) {
             gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true>(p2, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[2], ch.sync[2], it, tr);
         } else {
             gemm_dma_workgroup<true, true, EPI_UPDW, TAIL, 4, false>(p3, smem, s_rowvec, &s_arrivals, s_ticket, list, pos - ch.first[3], ch.sync[3], it, tr);
         }
-    }
-}
-
-// The same chain served by RESIDENT workgroups (gridDim.x / 8 per list, two per CU) that pull the items of their XCD's list through a ticket
-// counter until the whole call -- every stage of every iteration -- is done.  The hardware dispatcher hands workgroups to the eight XCDs
-// round-robin and IN ORDER: with items of different lengths (K2's are 110 us, K4's 300 us) and no launch boundary to re-align the XCDs,
-// a free slot on one XCD waits for a slot on another (timelines: 15-35 us gaps between successive workgroups of a slot, 1.6 resident
-// workgroups per CU on average instead of 2).  A ticket per XCD has no such coupling.  The next item is claimed while the current one
-// waits for its operands (gemm_sync_wait), so the claim's round trip is not on the critical path; claiming ONE item ahead cannot deadlock:
-// the lowest unfinished ticket of a list is always either running or the next item of a workgroup whose current (lower) item is finished.
-// The arguments live in device memory (written by gccnmf_chain_args_kernel on the same stream), not in the kernel-argument segment: as
-// kernel arguments they are loop invariants of the ticket loop, and the compiler keeps all four stages' worth of them live through every
-// tile program (483 spilled SGPRs, scratch reloads inside the k loops).  Read through a pointer that is laundered once per item, a tile
-// program holds only its own stage's values, as in the classic kernel.
-struct GemmChainBlock {
-    GemmArgs p[4];
-    GemmChain ch;
-};
-static_assert(sizeof(GemmChainBlock) <= 4096 && sizeof(GemmChainBlock) % 4 == 0, "");
-static __global__ void gccnmf_chain_args_kernel(GemmChainBlock b, unsigned* dst) {
-    const unsigned* src = (const unsigned*)&b;
-    for (int i = threadIdx.x; i < (int)(sizeof(GemmChainBlock) / 4); i += blockDim.x) dst[i] = src[i];
-}
-typedef const __attribute__((address_space(4))) GemmChainBlock* gemm_chain_block_ptr;
-
-template <bool TAIL>
-__global__ __launch_bounds__(256, 2) void gccnmf_gemm_chain_resident_kernel(const GemmChainBlock* block, unsigned* tickets) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * GemmDmaLds<4>::SBUF];
-    __shared__ __attribute__((aligned(16))) float s_rowvec[2 * 512];
-    __shared__ unsigned s_arrivals;
-    __shared__ int s_ticket[2];
-    __shared__ int s_claim[2];
-    const int list = (int)(blockIdx.x & 7);
-    const int wpl = (int)(gridDim.x >> 3);
-    int ticket = (int)(blockIdx.x >> 3);                    // the first item: static (the counter starts behind the resident workgroups)
-    int n = 0;
-    while (true) {
-        unsigned long long laundered = (unsigned long long)block;         // (an integer: a pointer cast there and back would fold away)
-        asm volatile("" : "+s"(laundered));
-        const gemm_chain_block_ptr a = (gemm_chain_block_ptr)laundered;     // constant address space: uniform scalar loads
-        const int per_it = a->ch.first[4];
-        if (ticket >= per_it * a->ch.iterations) break;
-        const int q = ticket / per_it;
-        const int pos = ticket - q * per_it, it = a->ch.it0 + q;
-        const bool tr = it == a->ch.trace_it;
-        unsigned* const tc = tickets + list;
-        int* const sc = s_claim + (n & 1);
-        if (pos < a->ch.first[1]) {
-            gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true, true>(*(const GemmArgs*)&a->p[0], smem, s_rowvec, &s_arrivals, s_ticket, list, pos,
-                                                                    *(const GemmSync*)&a->ch.sync[0], it, tr, tc, sc);
-        } else if (pos < a->ch.first[2]) {
-            gemm_dma_workgroup<false, false, EPI_UPDH, false, 4, true, true>(*(const GemmArgs*)&a->p[1], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[1],
-                                                                       *(const GemmSync*)&a->ch.sync[1], it, tr, tc, sc);
-        } else if (pos < a->ch.first[3]) {
-            gemm_dma_workgroup<true, false, EPI_DIV, TAIL, 4, true, true>(*(const GemmArgs*)&a->p[2], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[2],
-                                                                    *(const GemmSync*)&a->ch.sync[2], it, tr, tc, sc);
-        } else {
-            gemm_dma_workgroup<true, true, EPI_UPDW, TAIL, 4, false, true>(*(const GemmArgs*)&a->p[3], smem, s_rowvec, &s_arrivals, s_ticket, list, pos - a->ch.first[3],
-                                                                     *(const GemmSync*)&a->ch.sync[3], it, tr, tc, sc);
-        }
-        __syncthreads();            // every wave is through its epilogue (the staging buffers and s_rowvec are free), the claim is in LDS
-        ticket = wpl + __builtin_amdgcn_readfirstlane(*sc);
-        ++n;
     }
 }
 

@@ -49,7 +49,8 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {0, 0, 1, 1},                       // 18 persistent
     {1, 0, 1, 1},                       // 19 prefetch
     {1, 0, 1, 1},                       // 20 wide_update_w
-    {0, 0, 9, 0},                       // 21 chain: GEMMs chained in one launch (0 off, 2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call, 9 = 8 on resident workgroups)
+    {1, 0, 8, 0},                       // 21 chain: 1 = the whole call as one chained launch where the rule in chain_stages says so; 0 off; forced forms (tests, A/B):
+                                        //    2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call
     {0, 0, 1, 1},                       // 22 chain_solo: chained launches with one workgroup per CU (the freedom-from-deadlock test)
     {1, 0, 1, 0},                       // 23 chain_rag: chained launches on whole-file lists (0: the plain launch's lists, batch a multiple of 8 only)
     {0, 0, 1, 0},                       // 24 chain_local: ready counters through the XCD's L2 only (1) or agent scope (0)
@@ -91,7 +92,7 @@ int gccnmf_set_tuning(int key, int value) {
 #ifndef GCCNMF_EXPERIMENTS
     if (k.experiment) return GCCNMF_ERR_ARG;                 // the product build carries none of the code these select
 #endif
-    if (value < k.lo || value > k.hi || (key == 13 && value == 1) || (key == 21 && value != 0 && value != 2 && value != 4 && value < 8)) return GCCNMF_ERR_ARG;
+    if (value < k.lo || value > k.hi || (key == 13 && value == 1) || (key == 21 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)) return GCCNMF_ERR_ARG;
     gccnmf_knob_value[key].store(value, std::memory_order_relaxed);      // takes effect at the next library call (GccNmfCall)
     return GCCNMF_OK;
 }
@@ -843,7 +844,6 @@ static int launch_whdiv_rht(const NmfGeom& g, const float* V, const float* W, co
 // [batch][tiles_n] (K2 -> K3), c34 [batch] (K3 -> K4, items), c41 [batch] (K4 -> the next iteration's K1, items), error [1].  Zeroed once per gccnmf_klnmf call; iteration `it` waits for
 // (it + 1) x the per-iteration count, so nothing is reset between launches.
 static long chain_counter_floats(const NmfGeom& g, int batch) { return (long)batch * (2L * gccnmf_ceil_div(g.N, 64) + 2) + 32; }      // ... error [1], 7 unused, tickets [8], XCCs seen per list [8], 8 unused
-static const long chain_args_floats = 1024;          // behind the counters: the argument block of the resident chained grid (GemmChainBlock)
 static long klnmf_workspace_base_floats(const NmfGeom& g, int batch) {
     long n = (long)batch * (g.sV + g.sU + 3L * g.Kp);
     if (batch == 1) n += GCCNMF_SPLITS * ((g.sV > g.sU ? g.sV : g.sU) + (long)g.Kp);
@@ -855,14 +855,26 @@ static int chain_stages(const NmfGeom& g, int batch, int flags) {
     const int want = gccnmf_tune_chain;
     if (!want || !gccnmf_tune_dma || gccnmf_tune_tile_policy == 2 || gccnmf_tune_tail_split > 1) return 0;
     if (direct_path(g, batch) || (flags & 3) || batch < 8 || ((batch & 7) && !gccnmf_tune_chain_rag)) return 0;
-    if (g.K <= 256 || g.Fm <= 128 || g.Fm > 512 || (g.Fm & 127) || (g.K & 63) || (g.F % 16) != 1 || !g.tail) return 0;
+    // (K a multiple of 128: a K2 tile whose last wave is partly beyond M takes the generic epilogue h * (acc / den) for that wave, a plain
+    // launch on half-height tiles the lean one (h * acc) * (s / den) for the same rows: a few ulp apart, so the forms would not be bitwise equal)
+    if (g.K <= 128 || g.Fm <= 128 || g.Fm > 512 || (g.Fm & 127) || (g.K & 127) || (g.F % 16) != 1 || !g.tail) return 0;
     if (gccnmf_tune_tile_policy != 1 && (long)batch * gccnmf_ceil_div(g.N, 64) < 256) return 0;      // (the small-batch tile's territory)
     if (!can_fuse_w_update(g, batch)) return 0;
-    return want;
+    if (want != 1) return want;                                   // a forced form
+    // The rule (profiles/r06h_files_sweep_*.txt, one-stream iteration as a fraction of the f32 peak, plain launches -> whole-call chain):
+    //   24 files 0.74 -> 0.78, 32: 0.81 -> 0.85, 40: 0.73 -> 0.86, 64: 0.83 -> 0.86, 72: 0.79 -> 0.86, 104: 0.80 -> 0.86 -- but 16 files (two per XCD:
+    //   the four stages of so few files cannot fill 64 slots): 0.75 -> 0.59, and with whole-file lists the longest list sets the pace: 25
+    //   files (4 on one XCD, 3 on the others) 0.77 -> 0.68, 51: a tie, 52 (7 | 6): 0.75 -> 0.80.  So: at least three files per XCD and a longest
+    //   list at most 8 % above the mean.  Not beside another file group's launches (flag bit 2): two chained launches that share the chip
+    //   are slower than two plain ones (155 k against 158 k frames/s end to end).
+    if (flags & 4) return 0;
+    const int longest = (batch + 7) / 8;
+    if (batch < 24 || 100L * 8 * longest > 108L * batch) return 0;
+    return 8;
 }
 
 static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, float* W, float* H, float* R, float* colsumW, float* hscale,
-                              float alpha, float eps, int batch, int flags, unsigned* counters, int it0, int iterations, bool resident, hipStream_t s) {
+                              float alpha, float eps, int batch, int flags, unsigned* counters, int it0, int iterations, hipStream_t s) {
     GemmArgs a[4] = {};
     const int concurrent = (flags & 4) ? 1 : 0;
     for (int i = 0; i < 4; ++i) {
@@ -895,12 +907,14 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     a[3].tail_row = g.F - 1;
     a[3].C = W; a[3].sC = g.sW; a[3].ldc = g.Kp;
     a[3].out_colsum = colsumW; a[3].out_norm = hscale; a[3].s_out = g.Kp;
+    const int tm1 = g.K <= 256 ? 2 : 4;            // K2's outputs are the K atoms: at most 256 rows -> half-height tiles, as in a plain launch
     GemmChain ch = {};
     for (int i = 0; i < 4; ++i) {
         int len = 0;
         if (i < stages) {
             // whole-file lists (key 23, default): any batch size, K4 never waits for a ragged K3 item at the end of a list
-            const int grid = gemm_dma_plan(a[i], i != 3, 4, gccnmf_tune_chain_rag != 0);
+            const int tm = (i == 1 && tm1 == 2) ? 2 : 4;
+            const int grid = gemm_dma_plan(a[i], i != 3 && tm == 4, tm, gccnmf_tune_chain_rag != 0);
             if (grid < 8 || a[i].lists != 8 || a[i].split) return GCCNMF_ERR_ARG;
             len = grid / 8;
         }
@@ -928,14 +942,14 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
         ch.sync[2].sig_cnt = c34; ch.sync[2].sig_stride = 1; ch.sync[2].sig_per_tile = 0;
         ch.sync[3].wait_cnt = c34; ch.sync[3].wait_stride = 1; ch.sync[3].wait_per_tile = 0;
         ch.sync[3].wait_need = ch.sync[3].wait_need_last = (unsigned)(a[2].tiles_m * a[2].tiles_n);
-        if (iterations > 1 || resident) {
+        if (iterations > 1) {
             // K4 -> the next iteration's K1: every atom tile of the file (W, its column sums and the pending row scale are complete; R is free)
             ch.sync[3].sig_cnt = c41; ch.sync[3].sig_stride = 1; ch.sync[3].sig_per_tile = 0;
             ch.sync[0].wait_cnt = c41; ch.sync[0].wait_stride = 1; ch.sync[0].wait_per_tile = 0; ch.sync[0].wait_lag = 1;
             ch.sync[0].wait_need = ch.sync[0].wait_need_last = (unsigned)(a[3].tiles_m * a[3].tiles_n);
         }
     }
-    if ((iterations > 1 || resident) && stages != 4) return GCCNMF_ERR_ARG;
+    if (iterations > 1 && stages != 4) return GCCNMF_ERR_ARG;
     ch.it0 = it0; ch.iterations = iterations;
     ch.trace_it = it0 + iterations - 1;
     if ((long)8 * ch.first[4] * iterations > (1L << 30)) return GCCNMF_ERR_ARG;
@@ -946,26 +960,11 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     }
     const int grid = 8 * ch.first[4] * iterations;
     const unsigned pad = gccnmf_tune_chain_solo ? 16384u : 0u;         // static 78 KB + 16 KB: one workgroup per CU
-    if (resident) {
-        if (stages != 4 || !g.tail) return GCCNMF_ERR_ARG;
-        // two resident workgroups per CU (one with key 22), never more than there are items in a list
-        int wpl = gccnmf_tune_chain_solo ? 32 : 64;
-        if (wpl > ch.first[4] * iterations) wpl = ch.first[4] * iterations;
-        GemmChainBlock blk;
-        for (int i = 0; i < 4; ++i) blk.p[i] = a[i];
-        blk.ch = ch;
-        unsigned* dst = err + 32;                                     // (16-byte aligned: the workspace is, and every region before is a multiple of 4 floats... checked below)
-        if (((size_t)dst & 15) != 0) dst += (4 - (((size_t)dst >> 2) & 3)) & 3;
-        hipLaunchKernelGGL(gccnmf_chain_args_kernel, dim3(1), dim3(256), 0, s, blk, dst);
-        GCCNMF_CHECK_LAUNCH();
-        hipLaunchKernelGGL((gccnmf_gemm_chain_resident_kernel<true>), dim3(8 * wpl), dim3(256), pad, s, (const GemmChainBlock*)dst, err + 8);
-    } else if (stages == 2) {
-        if (g.tail) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 2>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
-        else return GCCNMF_ERR_ARG;
-    } else {
-        if (g.tail) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 4>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
-        else return GCCNMF_ERR_ARG;
-    }
+    if (!g.tail) return GCCNMF_ERR_ARG;
+    if (stages == 2 && tm1 == 4) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 2, 4>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
+    else if (stages == 2) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 2, 2>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
+    else if (tm1 == 4) hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 4, 4>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
+    else hipLaunchKernelGGL((gccnmf_gemm_chain_kernel<true, 4, 2>), dim3(grid), dim3(256), pad, s, a[0], a[1], a[2], a[3], ch);
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }
@@ -991,7 +990,7 @@ long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     NmfGeom g = make_geom(F, N, K);
     // R | U | colsumW | rowsumH | hscale | split-K scratch (one file) | Wt | Ht | Rt of the direct path (a handful of files at most) | chain counters
-    return klnmf_workspace_base_floats(g, batch) + chain_counter_floats(g, batch) + chain_args_floats;
+    return klnmf_workspace_base_floats(g, batch) + chain_counter_floats(g, batch);
 }
 
 // One launch group of the iteration, addressable on its own so that tests and the benchmark can time /
@@ -1092,12 +1091,14 @@ static int klnmf_stage(int stage, const float* V, float* W, float* H, float* wor
 }
 
 // Which launches gccnmf_klnmf would use for this problem under the current tuning: bit 0 the direct latency kernels, bit 1 the fused
-// K1 + K2 launch, bit 2 the fused K3 + K4a slab launch (benchmarks and tests name the kernel they time by this).
+// K1 + K2 launch, bit 2 the fused K3 + K4a slab launch, bit 3 chained launches of the iteration (benchmarks and tests name the kernel they
+// time by this; the engine keeps ONE file group when the library chains).
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
     GCCNMF_ENTER();
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     const NmfGeom g = make_geom(F, N, K);
-    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht_files(g, batch, flags) > 0 ? 4 : 0);
+    return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht_files(g, batch, flags) > 0 ? 4 : 0) |
+           (chain_stages(g, batch, flags) ? 8 : 0);
 }
 
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
@@ -1121,11 +1122,11 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     float* R = workspace;
     float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;
     float* hscale = colsumW + 2L * batch * g.Kp;
-    if (chained >= 8 && iterations > 0) {
-        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, 0, iterations, chained == 9, s))) return rc;
+    if (chained == 8 && iterations > 0) {
+        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, 0, iterations, s))) return rc;
     } else {
         for (int it = 0; it < iterations; ++it) {
-            if (chained && (rc = launch_klnmf_chain(chained, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, it, 1, false, s))) return rc;
+            if (chained && (rc = launch_klnmf_chain(chained, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, it, 1, s))) return rc;
             for (int stage = chained + 1; stage <= 5; ++stage)
                 if ((rc = klnmf_stage(stage, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
         }
@@ -1480,7 +1481,7 @@ int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurre
     if (M < 1 || N < 1 || batch < 1 || !plan || (max_items > 0 && !items)) return -1;
     GemmArgs a = {};
     a.M = M; a.N = N; a.batch = batch; a.xcd_affine = xcd_affine; a.concurrent = concurrent;
-    const int grid = gemm_dma_plan(a, narrow_capable != 0, 4);
+    const int grid = gemm_dma_plan(a, (narrow_capable & 1) != 0, 4, (narrow_capable & 2) != 0);      // bit 1: the whole-file lists of chained launches
     if (grid < 1) return -1;
     const int fields[8] = {a.lists, a.cw, a.cr, a.split, a.rag, a.tiles_m, a.tiles_n, grid};
     for (int i = 0; i < 8; ++i) plan[i] = fields[i];

@@ -119,6 +119,12 @@ class GCCNMFEngine(object):
             tiles_wh = -(-(2 * num_frames(self.n_samples, self.n_fft, self.hop)) // 64)
             atoms = -(-int(dictionarySize) // 64)
             nmf_groups = 2 if (self.batch % 2 == 0 and half >= 16 and half * tiles_wh >= 256 and half * atoms >= 256) else 1
+            # Round 6: where the library runs the whole KL-NMF call as ONE chained launch (gccnmf_klnmf_plan bit 3: tiles handed over
+            # between the GEMMs through ready counters, no launch boundaries left to overlap), one group is as fast as two plain ones at
+            # 64 files and faster everywhere else (40 files: 134 k -> 156 k frames/s) -- and a second chained launch beside it only costs.
+            Fq, Nq = int(windowSize) // 2 + 1, 2 * num_frames(self.n_samples, self.n_fft, self.hop)
+            if nmf_groups > 1 and Nq > 0 and self.lib.gccnmf_klnmf_plan(Fq, Nq, int(dictionarySize), self.batch, klnmf_flags) & 8:
+                nmf_groups = 1
         if nmf_groups < 1 or self.batch % nmf_groups:
             raise ValueError('nmf_groups must divide the batch')
         self.nmf_groups = int(nmf_groups)

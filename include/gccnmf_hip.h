@@ -46,33 +46,32 @@ extern "C" {
 
 int gccnmf_version(void);
 
-/* Experiment knobs (process-global).  key 1: ablation bits of the REGISTER-STAGED GEMM kernel (results become INVALID while
- * non-zero; the LDS-DMA kernel ignores them) -- 1 no global loads, 2 no LDS stores, 4 no k-loop barrier, 8 no tail row,
- * 16 no epilogue.  key 2: GEMM tile policy -- 0 automatic (by launch size), 1 always the 512x64 throughput tile,
- * 2 always the 128x64 small-batch tile (results stay valid; used by the tests to cover both paths at any size).
- * key 3: 1 (default) = the throughput-tile GEMMs of the KL-NMF loop stage operands by LDS-DMA (global_load_lds, csrc/gemm_dma.h)
- * (0: through registers, csrc/gemm_mfma.h; results stay valid; only the summation order inside a 16-deep k-tile differs).
- * key 4: 1 (default) = small launches run on the LDS-DMA ring kernel (csrc/gemm_ring.h).  keys 5 / 6: parts of the single-file
- * split-K reductions (W.H / R.H^T).  key 7: 1 (default) = the throughput tile's V / (W.H) epilogue divides IEEE-exactly like numpy.divide
- * (0: v_rcp_f32 + one Newton step through the exact fma residual -- correctly rounded except for rare 1-ulp cases; the exact form was
- * measured to cost nothing in the MFMA-bound launch, round 5; the small-launch kernels always divide exactly).  key 8: at most that many file groups (1..4, default 3) of a shard that cannot fill the chip
- * by itself run on separate streams between two W updates (the library owns the side streams; results are bitwise the one-stream ones).
- * key 9: 1 (default) = a throughput-tile launch that has the chip to itself is laid out by a cost model: full 512 x 64 tiles, or whole
- * rounds of them plus the remaining FILES as a second launch of half-height (256 x 64) tiles, or half-height tiles throughout; outputs
- * of at most 256 rows always take half-height tiles; a file's ragged last column tile (at most 32 of its 64 columns exist: N = 1244)
- * becomes a NARROW (512 x 32) item at the end of its XCD's list when that does not cost the launch another round of workgroup slots.
- * Same k order per element: bitwise the same results in every form.  0 = full tiles only; 2 = every full tile as two narrow halves, 3 = half-height tiles everywhere (tests / measurements).
- * key 10: 1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register GEMM
- * kernels of csrc/direct.hip (gccnmf_gemm_direct below); 0 = the round-3 split-K / ring-kernel path.  key 11: 0 (default) = the direct
- * kernels' tile by the cost model, 1..8 = that tile everywhere (experiments).  key 12: largest batch on the direct path (1..8, default 4).
- * key 13: register sets of the direct kernels' operand pipeline (0 = by tile, 2..4).  key 14: 1 (default) = H updates of at most 128
- * atoms run on the ring kernel's 128 x 64 tiles instead of the register-staged 128 x 256 tile.
- * keys 16 / 17: short dictionaries (K <= 128: the reference driver's K = 128, runGCCNMF.py:41), F = 64 n + 1 <= 513 -- two launches of an
- * iteration become one and R is never written (csrc/direct.hip).  key 16: K1 + K2 as ONE launch of 64-frame column tiles that keep their
- * scaled H in registers and stream W through LDS.  key 17: K3 + K4a as ONE launch of 64-bin slabs that keep their W rows in registers and
- * stream H through LDS.  Values: 0 never, 1 (default) when a cost model of whole rounds of 512 workgroups says it beats the two launches
- * (from about 50 files per GPU at N = 1244), 2 whenever the shape allows.  gccnmf_klnmf_plan reports the choice.
- * Unknown keys / values: GCCNMF_ERR_ARG. */
+/* Tuning knobs: process-global atomics; every library call works on a snapshot taken at its entry.  Results stay valid (and, where a
+ * knob only changes the launch form, bitwise the same) for every value of a PRODUCT key.  Keys marked X exist only in the lab build
+ * (make EXPERIMENTS=1 -> libgccnmf_hip_exp.so): the product library rejects them with GCCNMF_ERR_ARG and carries none of the code they
+ * select.  The authoritative table (defaults, ranges) is csrc/common.h.
+ *   2  GEMM tile policy: 0 by launch size, 1 always the 512 x 64 throughput tile, 2 always the 128 x 64 small-batch tile (tests cover both)
+ *   3  1 (default) = throughput tiles stage operands by LDS-DMA (csrc/gemm_dma.h), 0 = through registers (csrc/gemm_mfma.h)
+ *   7  1 (default) = V / (W.H) is the IEEE quotient like numpy.divide, 0 = v_rcp_f32 + one Newton step (rare 1-ulp differences)
+ *   8  file groups (1..4, default 3) of a shared-dictionary shard that cannot fill the chip, on library-owned streams
+ *   9  throughput-tile launch forms: 1 (default) by the launcher's cost model -- full tiles | whole rounds of full tiles + the remaining files
+ *      half-height | half-height throughout; outputs of at most 256 rows always half-height; a file's ragged last column tile (at most 32 of its
+ *      64 columns exist: N = 1244) as a NARROW 512 x 32 item -- 0 = full tiles only, 2 = every tile as two narrow halves, 3 = half-height
+ *      everywhere (tests).  Same k order per element: bitwise the same in every form.
+ *  10  1 (default) = launches that cannot fill the chip (one mixture alone, up to key-12 files) take the direct-to-register kernels
+ *      (csrc/direct.hip); 0 = the ring (csrc/gemm_ring.h) and throughput kernels.   12  largest batch on the direct path (1..8, default 4)
+ *  16 / 17  short dictionaries (K <= 128, F = 64 n + 1 <= 513): K1 + K2 as one launch of column tiles / K3 + K4a as one launch of bin slabs
+ *      (R never written): 0 never, 1 (default) by a cost model in rounds of 512 workgroups, 2 whenever the shape allows
+ *  21  batch scale, K > 256: 1 (default) = the whole gccnmf_klnmf call -- every GEMM of every iteration -- as ONE chained launch whose
+ *      workgroups hand tiles over through ready counters in their XCD's L2 (csrc/gemm_dma.h: GemmSync), where that wins: at least three files
+ *      per XCD, balanced whole-file lists, no other file group beside it; 0 = never; forced forms for tests and A/B runs: 2 = K1 | K2, 4 = the
+ *      four GEMMs of an iteration, 8 = every iteration of the call.  Bitwise the same factors in every form.
+ *  23  1 (default) = chained launches on whole-file lists (any batch size); 0 = on the plain launch's lists (batch a multiple of 8)
+ *  24  1 = the ready counters of chained launches stay in the XCD's own L2 (default 0: agent scope; measured equal)
+ *   X  1 ablations of the register-staged kernel (results INVALID), 4 ring kernel off, 5 / 6 parts of the round-3 single-file split-K, 11 / 13
+ *      fixed tile / pipeline depth of the direct kernels, 14 short H updates off the ring kernel, 15 one FFT stage per LDS round trip, 18 / 19
+ *      resident-workgroup grid and its prefetch, 20 the 16-atom W update, 22 chained launches with one workgroup per CU
+ * gccnmf_klnmf_plan reports what a call would launch.  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 
 /* Padded geometry every other entry point assumes. */
@@ -385,6 +384,8 @@ int gccnmf_gemm_direct(const gccnmf_direct_gemm* desc, int epilogue, int tile, v
  * over `batch` files under the current tuning -- the SAME tile decode the kernel runs, executed on the host.
  *   plan  [8]: lists, wide tiles per list, ragged narrow tiles per list, split, rag, tiles_m, tiles_n, items of the classic grid
  *   items [max_items][6]: list, ticket, file, row tile, first column, column blocks (2 = 512 x 64, 1 = a narrow 512 x 32 item)
+ *   narrow_capable: bit 0 = the kernel instantiation carries the narrow loop, bit 1 = the whole-file lists of chained launches (list x =
+ *   files x, x + 8, ..., each file's wide tiles followed by its ragged items; plan[1] = items of the longest list)
  * Returns the number of items (all lists), -1 on bad arguments. */
 int gccnmf_debug_gemm_plan(int M, int N, int batch, int xcd_affine, int concurrent, int narrow_capable, int* plan, int* items, int max_items);
 

@@ -355,7 +355,14 @@ def test_nmf_file_groups_on_streams_are_bitwise_the_single_stream_result():
     e1 = engine(32000, nmf_groups=1, **kw)
     y1 = e1.separate(xs)
     assert engine(32000, **kw).nmf_groups == 1          # K = 128: a half batch would no longer fuse / fill the chip like the whole
-    assert engine(160000, dictionarySize=1024, numIterations=1, batch=32).nmf_groups == 2
+    # K = 1024: the library runs the call as ONE chained launch (round 6) -- one group; without chaining the engine splits the batch in two
+    from gcc_nmf_amd import _hip
+    assert engine(160000, dictionarySize=1024, numIterations=1, batch=32).nmf_groups == 1
+    try:
+        assert _hip.lib().gccnmf_set_tuning(21, 0) == 0
+        assert engine(160000, dictionarySize=1024, numIterations=1, batch=32).nmf_groups == 2
+    finally:
+        _hip.lib().gccnmf_set_tuning(21, 1)
     for groups in (2, 4):
         eg = engine(32000, nmf_groups=groups, **kw)
         assert eg.nmf_groups == groups

@@ -58,7 +58,7 @@ def test_pitches_and_workspace_sizes():
     assert lib.gccnmf_pitches(1, 622, 128, *[ctypes.byref(x) for x in v]) == 1           # GCCNMF_ERR_ARG
     base = 528 * 1280 + 528 * 1024 + 3 * 1024                      # R, U, three K-vectors per file
     direct = 1024 * 528 + 1280 * 1024 + 1280 * 528                 # Wt, Ht, Rt: the transposed copies of the direct path, per file
-    chain = lambda batch: batch * (2 * 20 + 2) + 32 + 1024         # (+ the argument block of the resident chained grid) ready counters of the chained launches (K1 -> K2, K2 -> K3 per column tile; K3 -> K4, K4 -> K1 per file) + error flag
+    chain = lambda batch: batch * (2 * 20 + 2) + 32                # ready counters of the chained launches (K1 -> K2, K2 -> K3 per column tile; K3 -> K4, K4 -> K1 per file) + error flag
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 2) == 2 * (base + direct) + chain(2)
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 64) == 64 * base + chain(64)               # (a handful of files at most)
     assert lib.gccnmf_klnmf_workspace_floats(513, 1244, 1024, 1) == base + 4 * (528 * 1280 + 1024) + direct + chain(1)      # + the split-K partials of one file alone
@@ -158,13 +158,60 @@ def test_throughput_tile_work_lists_cover_every_tile_exactly_once():
     assert lib.gccnmf_debug_gemm_plan(0, 5, 1, 1, 0, 1, None, None, 0) == -1
 
 
+def test_chained_launch_lists_hold_whole_files():
+    """The lists of a chained launch (gccnmf_debug_gemm_plan, narrow_capable bit 1): every item of a file sits in ONE list -- list
+    file % 8, so that every producer and consumer of a file share one XCD's L2 in every GEMM of the iteration -- the files of a list in
+    ascending order, a file's items together (wide tiles, then its ragged ones), every 32-column block computed exactly once, at any
+    batch size; the longest list has ceil(batch / 8) files."""
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    for M, N, B, narrow in [(512, 1244, 64, 1), (1024, 1244, 64, 1), (512, 1024, 64, 0), (512, 1244, 26, 1), (1024, 1244, 77, 1), (512, 1280, 13, 1),
+                            (512, 1244, 8, 1), (1536, 660, 50, 1)]:
+        pl, items = _gemm_plan(lib, M, N, B, narrow=narrow | 2)
+        assert pl['lists'] == 8 and pl['split'] == 0 and pl['cr'] == 0
+        assert pl['cw'] == -(-B // 8) * pl['tiles_m'] * pl['tiles_n'] and pl['grid'] == 8 * pl['cw']
+        cover = np.zeros((B, pl['tiles_m'], 2 * pl['tiles_n']), int)
+        for lst, t, f, tm, c0, nw in items:
+            assert f % 8 == lst and nw in (1, 2)
+            cover[f, tm, c0 // 32: c0 // 32 + nw] += 1
+        need = np.ones_like(cover)
+        if pl['rag']:
+            need[:, :, -1] = 0
+            assert narrow and N - 64 * (pl['tiles_n'] - 1) <= 32
+        assert np.array_equal(cover, need), (M, N, B)
+        per = pl['tiles_m'] * pl['tiles_n']
+        for lst in range(8):
+            mine = items[items[:, 0] == lst]
+            assert np.array_equal(mine[:, 1], np.arange(len(mine))) and len(mine) == per * len(range(lst, B, 8))
+            assert np.array_equal(mine[:, 2], np.repeat(np.arange(lst, B, 8), per))           # whole files, ascending
+            for q in range(len(mine) // per):
+                assert np.all(np.diff(mine[q * per:(q + 1) * per, 5]) <= 0)                    # a file's ragged items behind its wide ones
+    try:
+        assert lib.gccnmf_set_tuning(9, 2) == 0
+        assert lib.gccnmf_debug_gemm_plan(512, 1244, 64, 1, 0, 3, (ctypes.c_int * 8)(), None, 0) == -1       # no chained form of the all-halves test layout
+    finally:
+        lib.gccnmf_set_tuning(9, 1)
+    assert lib.gccnmf_debug_gemm_plan(512, 1244, 5, 1, 0, 3, (ctypes.c_int * 8)(), None, 0) == -1           # fewer than 8 files: one list, no chain
+
+
 def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
     """gccnmf_klnmf_plan: which launches gccnmf_klnmf will use (no device needed).  Short dictionaries at batch scale take the fused
     launches when whole rounds of 512 workgroups pay; file groups that run side by side (GCCNMF_FLAG_GROUPS) are planned together."""
     from gcc_nmf_amd import _hip
     lib = _hip.lib()
     plan = lib.gccnmf_klnmf_plan
-    assert plan(513, 1244, 1024, 1, 0) == 1 and plan(513, 1244, 1024, 4, 0) == 1 and plan(513, 1244, 1024, 64, 0) == 0     # direct path: up to 4 files
+    assert plan(513, 1244, 1024, 1, 0) == 1 and plan(513, 1244, 1024, 4, 0) == 1 and plan(513, 1244, 1024, 64, 0) == 8     # direct path: up to 4 files
+    # bit 3: the whole call as one chained launch -- K > 256, at least three files per XCD, the longest whole-file list at most 8 % above
+    # the mean, no other file group beside it (round 6, profiles/r06h_files_sweep_*.txt)
+    assert [plan(513, 1244, 1024, b, 0) for b in (16, 24, 25, 26, 32, 51, 52, 77, 104)] == [0, 8, 0, 0, 8, 0, 8, 8, 8]
+    assert plan(513, 1244, 1024, 32, 4 | (2 << 8)) == 0 and plan(513, 1244, 128, 64, 0) & 8 == 0 and plan(513, 1244, 256, 64, 0) == 8 and plan(513, 1244, 320, 64, 0) == 0 and plan(513, 1244, 384, 64, 0) == 8
+    assert plan(513, 1244, 1024, 64, 1) == 0 and plan(513, 1244, 1024, 64, 2) == 0              # no XCD-affine lists / unfused W update: plain launches
+    try:
+        assert lib.gccnmf_set_tuning(21, 0) == 0 and plan(513, 1244, 1024, 64, 0) == 0
+        assert lib.gccnmf_set_tuning(21, 4) == 0 and plan(513, 1244, 1024, 16, 0) == 8 and plan(513, 1244, 1024, 25, 4 | (2 << 8)) == 8     # forced form
+        assert lib.gccnmf_set_tuning(21, 3) == 1
+    finally:
+        lib.gccnmf_set_tuning(21, 1)
     assert plan(513, 1244, 128, 64, 0) == 6 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
     assert plan(513, 1244, 128, 96, 0) == 6 and plan(513, 1244, 128, 128, 0) == 6                # 96: a round of 64 files on the slabs, 32 behind it
     assert plan(513, 1244, 129, 64, 0) == 0 and plan(500, 1244, 128, 64, 0) == 0                # K > 128 / F not 64 n + 1: the batched tiles
@@ -351,3 +398,29 @@ def test_lds_dma_statements_set_m0_themselves():
             elif re.search(r'\bm0\b', strings):
                 raise AssertionError('%s: an asm statement touches m0 without being an LDS-DMA load: %s' % (name, strings))
     assert dma >= 2
+
+
+def test_reciprocal_forms_of_the_update_epilogues_against_the_reference_quotients():
+    """only V / (W.H) is an IEEE quotient on the device; the other three divisions of gccNMFFunctions.py:76-80 are
+    evaluated by the lean epilogues (csrc/gemm_dma.h) as products with a correctly rounded reciprocal, and K2 associates differently:
+        H update (:76)    reference (H s) * (num / den)      device (H * num) * (s * (1 / den))      s = the pending norms of :81
+        W update (:77)    reference W * (num / den)          device W * (num * (1 / den))
+        normalise (:80)   reference W / norm                 device W * (1 / norm)
+    The same float32 expressions evaluated here in NumPy on 4 M random operands of the magnitudes the iteration sees: the distance to the
+    reference's expression is at most 1 ulp (normalise), 2 ulp (W update), 4 ulp (H update; 99.8 % within 2) -- 5e-7 relative at worst, against
+    the 1e-4 bar on W and H after 100 iterations."""
+    rng = np.random.default_rng(0)
+    n = 4_000_000
+    f = np.float32
+
+    def ulps(a, b):
+        return np.abs(a.astype(f).view(np.int32).astype(np.int64) - b.astype(f).view(np.int32).astype(np.int64))
+    h = rng.random(n, dtype=f) + f(1e-3)
+    num = rng.random(n, dtype=f) * f(50) + f(0.01)
+    den = rng.random(n, dtype=f) * f(30) + f(0.5)
+    s = rng.random(n, dtype=f) * f(3) + f(0.1)
+    one = f(1)
+    d_h = ulps((h * num) * (s * (one / den)), (h * s) * (num / den))
+    d_w = ulps(h * (num * (one / den)), h * (num / den))
+    d_n = ulps(num * (one / den), num / den)
+    assert d_n.max() <= 1 and d_w.max() <= 2 and d_h.max() <= 4 and (d_h <= 2).mean() > 0.995
