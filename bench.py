@@ -787,6 +787,32 @@ def main():
             'driver_shape_hop128_K128': {'copying': dropin_sequence(dev1_mixture(), sr, 128, 128), 'resident': dropin_sequence(dev1_mixture(), sr, 128, 128, resident=True)},
             'config2_hop256_K1024': {'copying': dropin_sequence(dev1_mixture(), sr, 256, 1024), 'resident': dropin_sequence(dev1_mixture(), sr, 256, 1024, resident=True)}}
 
+    if rank == 0 and world == 1 and not a.skip_extras and (K, iters, a.hop, a.seconds) == (1024, 100, 256, 10.0):
+        # mixtures of DIFFERENT lengths in one batch (runGCCNMF.py:30-36 takes a file of any length): 21 x 5 s + 21 x 10 s + 22 x 15 s, KL-NMF over
+        # all 64 files in one ragged chained launch, against the equal-length rate of this run at (nearly) the same total frames
+        from gcc_nmf_amd.engine import RaggedGCCNMFEngine
+        from gcc_nmf_amd.synthetic import synthetic_mixture
+        lengths = ([80000, 160000, 240000] * 22)[:64]
+        mix = [synthetic_mixture(2000 + i, numSamples=m, sampleRate=sr) for i, m in enumerate(lengths)]
+        er = RaggedGCCNMFEngine(lengths, sampleRate=sr, windowSize=1024, hopSize=a.hop, numTDOAs=128, microphoneSeparationInMetres=1.0, numTargets=3,
+                                dictionarySize=K, numIterations=iters, device='cuda:%d' % local_rank)
+        er.upload(mix)
+        er.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            er.run()
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - t1) / 3
+        for sub in er.sub.values():
+            sub.check_status()
+        out['mixed_lengths'] = {'files': 64, 'seconds_per_file': {'5': lengths.count(80000), '10': lengths.count(160000), '15': lengths.count(240000)},
+                                'frames': int(sum(er.frames)), 'ms_per_step': 1e3 * dtr, 'frames_per_s': sum(er.frames) / dtr,
+                                'one_ragged_launch': er.ragged_klnmf_used, 'vs_equal_length_rate': sum(er.frames) / dtr / (frames / elapsed),
+                                'what': 'HBM-resident, like `value`: samples in HBM -> waveforms in HBM; KL-NMF of all 64 files in ONE chained launch '
+                                        '(gccnmf_klnmf_ragged: per-file column tiles, files dealt out to the XCDs by length), the one-shot stages per length'}
+        del er
+
     if rank == 0 and world == 1 and not a.skip_extras and not a.skip_config_lines and (K, iters, a.hop, a.seconds) == (1024, 100, 256, 10.0):
         t1 = time.perf_counter()
         out.update(config_lines(a, e, xs, sr, n, local_rank))

@@ -412,7 +412,41 @@ __host__ __device__ __forceinline__ int gemm_dma_list_file(const GemmArgs& p, in
     const int cls = q < big ? q / (n_full + 1) : rem + (q - big) / n_full;
     return cls + 8 * (q < big ? q - cls * (n_full + 1) : (q - big) - (cls - rem) * n_full);
 }
+// a file's last column tile is ragged -- at most 32 of its 64 columns exist -- and the launch may run it as a narrow item
+__host__ __device__ __forceinline__ bool gemm_dma_file_rag(int narrow_ok, int n) {
+    const int tn = (n + 63) >> 6;
+    return narrow_ok && tn >= 2 && n - (tn - 1) * 64 <= 32;
+}
 __host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int list, int t, int& file, int& tm, int& col0, int& nw) {
+    if (p.ragged_n) {
+        // a ragged batch: the list names its files (balanced by the host over the eight lists); a file contributes tiles_m x its own column tiles
+        // (K1 - K3), or the uniform tiles_m x tiles_n atom tiles with its own reduction length (K4).  Same order inside a file as below.
+        const int* L = p.ragged_lists + list * (GEMM_RAGGED_LMAX + 1);
+        const int cnt = L[0];
+        int acc = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const int f = L[1 + k];
+            const int n = p.ragged_kd ? p.N : p.ragged_n[f];
+            const int tn = (n + 63) >> 6, per = p.tiles_m * tn;
+            if (t < acc + per) {
+                const int w = t - acc;
+                const int wide_n = tn - (gemm_dma_file_rag(p.narrow_ok, n) ? 1 : 0), wt = p.tiles_m * wide_n;
+                if (w < wt) {
+                    tm = w / wide_n;
+                    col0 = (w - tm * wide_n) * 64;
+                    nw = 2;
+                } else {
+                    tm = w - wt;
+                    col0 = (tn - 1) * 64;
+                    nw = 1;
+                }
+                file = f + p.file0;
+                return true;
+            }
+            acc += per;
+        }
+        return false;
+    }
     const int wt = p.tiles_m * p.wide_n;                      // wide tiles per file
     if (p.whole_files) {
         // chained launches: every producer and consumer of a file must run on ONE XCD in every GEMM of the iteration, whatever the batch
@@ -489,24 +523,26 @@ struct GemmSync {
     unsigned* sig_cnt;                   // producer side: nullptr = nothing waits for this stage inside the launch
     int wait_stride, sig_stride;         // counters per file
     int wait_per_tile, sig_per_tile;     // 1: counter (file, column tile), the producer adds the item's 32-column blocks (nw); 0: counter (file), + 1 per item
-    unsigned wait_need, wait_need_last;  // producer counts PER ITERATION the consumer waits for; _last: for the consumer's column tile `last_tile`
-    int last_tile;
+    unsigned wait_need;                  // producer counts PER ITERATION the consumer waits for: per column tile 2 x the producer's row tiles (32-column blocks), halved
+                                         // for a file's ragged last tile when the producer runs it as ONE narrow item (prod_narrow); per file the producer's items
+    int prod_narrow;
+    int wait_scale_tiles;                // per-file counter of a ragged batch: wait_need is the count per COLUMN TILE of the file (x its own number of tiles)
     int wait_lag;                        // 0: the producer runs in the same iteration (waits for need x (it + 1)); 1: in the previous one (need x it: K4 -> K1)
-    int local;                           // 1: counter traffic stays in the XCD's L2 (atomic add without a scope, polls that only bypass the L1): ~0.5 us per
-                                         //    poll instead of ~3 us for the agent-scope pair, which goes to the memory side
     unsigned* error;
     unsigned* xcc_seen;                  // [list]: bit x set by every workgroup of the list that ran on XCC x -- checked after the call (one bit per list)
 };
 #define GEMM_SYNC_TIMEOUT 2000000LL      // s_memrealtime ticks (100 MHz): 20 ms, a whole chained launch is ~1-3 ms
 
-__device__ __forceinline__ unsigned gemm_sync_peek(const unsigned* counter, int local) {
+// Agent scope on both sides (the pair the compiler emits for agent-scope relaxed atomics): ~3 us per poll.  The cheaper XCD-local pair -- an
+// atomic add without a scope, polls that only bypass the L1 (sc0) -- was tried and does NOT hand over reliably: consumers timed out (round 6).
+__device__ __forceinline__ unsigned gemm_sync_peek(const unsigned* counter) {
     unsigned v;
-    if (local) asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(counter) : "memory");
-    else asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(counter) : "memory");
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(counter) : "memory");
     return v;
 }
 // it: the iteration this workgroup belongs to, counted from the zeroing of the counters.
-__device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int col0, int tid, int it, int list) {
+// n_file: the file's column count in the producer's GEMM (K1 - K3: N_f)
+__device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int col0, int tid, int it, int list, int n_file) {
     if (y.xcc_seen && tid == 0) {        // the hand-over relies on a list's workgroups sharing ONE XCD's L2: recorded here (no return, no wait), judged after the call
         const unsigned bit = 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);      // HW_REG_XCC_ID
         asm volatile("global_atomic_or %0, %1, off sc1" : : "v"(y.xcc_seen + list), "v"(bit) : "memory");
@@ -515,9 +551,16 @@ __device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int 
         if (tid == 0) {
             const int tile = col0 >> 6;
             const unsigned* c = y.wait_cnt + (long)file * y.wait_stride + (y.wait_per_tile ? tile : 0);
-            const unsigned need = ((y.wait_per_tile && tile == y.last_tile) ? y.wait_need_last : y.wait_need) * (unsigned)(it + 1 - y.wait_lag);
+            const int tn = (n_file + 63) >> 6;
+            unsigned need = y.wait_need;
+            if (y.wait_per_tile) {
+                if (tile == tn - 1 && gemm_dma_file_rag(y.prod_narrow, n_file)) need >>= 1;
+            } else if (y.wait_scale_tiles) {
+                need *= (unsigned)tn;
+            }
+            need *= (unsigned)(it + 1 - y.wait_lag);
             const long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (gemm_sync_peek(c, y.local) < need) {
+            while (gemm_sync_peek(c) < need) {
                 __builtin_amdgcn_s_sleep(16);
                 if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GEMM_SYNC_TIMEOUT) {
                     *y.error = 1u;
@@ -537,8 +580,7 @@ __device__ __forceinline__ void gemm_sync_signal(const GemmSync& y, int file, in
         if (tid == 0) {
             unsigned* c = y.sig_cnt + (long)file * y.sig_stride + (y.sig_per_tile ? (col0 >> 6) : 0);
             const unsigned n = y.sig_per_tile ? (unsigned)nw : 1u;
-            if (y.local) asm volatile("global_atomic_add %0, %1, off" : : "v"(c), "v"(n) : "memory");
-            else asm volatile("global_atomic_add %0, %1, off sc1" : : "v"(c), "v"(n) : "memory");
+            asm volatile("global_atomic_add %0, %1, off sc1" : : "v"(c), "v"(n) : "memory");
         }
     }
 }
@@ -579,6 +621,9 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
 #endif
 
     // ---- per-item state (set by take_item) ----
+    int nkt = (p.Kd + BK - 1) / BK;                 // (per item in a ragged K4: the file's own reduction length)
+    int n_item = p.N;                               // columns of the item's file (per item in a ragged K1 - K3)
+    int n_sync = p.N;                               // the file's column count in the GEMMs that hand over per column tile (what a consumer's wait is sized by)
     int file = 0, tm = 0, col0 = 0, nw = 2, row0 = 0;
     const float* __restrict__ A = nullptr;
     const float* __restrict__ B = nullptr;
@@ -597,6 +642,12 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
         tm = __builtin_amdgcn_readfirstlane(tm_);
         col0 = __builtin_amdgcn_readfirstlane(c_);
         nw = NARROW ? __builtin_amdgcn_readfirstlane(nw_) : 2;
+        if (p.ragged_n) {
+            const int nf = __builtin_amdgcn_readfirstlane(p.ragged_n[file]);
+            n_sync = nf;
+            if (p.ragged_kd) nkt = (nf + BK - 1) / BK;
+            else n_item = nf;
+        }
         row0 = tm * BM;
         A = p.A + file * p.sA;
         B = p.B + file * p.sB;
@@ -635,7 +686,6 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
     f32x16 acc[TM][2];
     float tail_acc = 0.f, rowsum_acc = 0.f;
 
-    const int nkt = (p.Kd + BK - 1) / BK;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(gemm_lds_ptr)smem);
     // the two 64-byte side chunks (tail row of A, row scale of B) sit next to each other behind the B tile: ONE piece of wave 0,
     // lanes 0-3 fetch the tail chunk, lanes 4-7 the scale chunk -- both land at (tail chunk) + 16 * lane
@@ -929,7 +979,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
 #else
         set_lane_constants(tid);
 #endif
-        gemm_sync_wait(sync, file, col0, tid, sync_it, list);   // chained launch: this item's operands come from an earlier stage of the same launch
+        gemm_sync_wait(sync, file, col0, tid, sync_it, list, n_sync);   // chained launch: this item's operands come from an earlier stage of the same launch
         if (trace_row && tid == 0) trace_row[1] = __builtin_amdgcn_s_memrealtime();      // [1] - [0] = time spent waiting for a producer
         // ---- prologue: tile 0 -> buffer 0 (unless the previous item's epilogue already sent it), group 0 of tile 0 into registers
         if (!prefetched) {
@@ -976,7 +1026,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
         if (trace_row && tid == 0) trace_row[2] = __builtin_amdgcn_s_memrealtime();
 
         // ---- the finished item's coordinates move aside; the next item's operands are set up (and requested) before the epilogue
-        const int e_file = file, e_row0 = row0, e_col0 = col0, e_nw = nw;
+        const int e_file = file, e_row0 = row0, e_col0 = col0, e_nw = nw, e_n = n_item;
         const bool e_active = wave_active, e_tail = do_tail, e_rowsum = do_rowsum;
         have = false;
         prefetched = false;
@@ -1005,14 +1055,14 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
                     if (lean) {
                         GemmEpiloguePair<EPI, BM> e0, e1;
                         const int ca = e_col0 + l31, tr = wm * RW;
-                        const bool oka = ca < p.N, okb = (!NARROW || e_nw == 2) && ca + 32 < p.N;
+                        const bool oka = ca < e_n, okb = (!NARROW || e_nw == 2) && ca + 32 < e_n;
                         const long cb = 4L * p.ldc * (p.M + (TAIL ? 1 : 0));
                         float ba = 0.f, bb = 0.f;
                         e0.load(p, e_file, row_w, hh, ca, cb);
                         e1.load(p, e_file, row_w + 32, hh, ca, cb);
                         if (EPI != EPI_DIV && p.ktailA) {
-                            ba = p.ktailB[e_file * p.s_ktailB + min(ca, p.N - 1)];
-                            bb = p.ktailB[e_file * p.s_ktailB + min(ca + 32, p.N - 1)];
+                            ba = p.ktailB[e_file * p.s_ktailB + min(ca, e_n - 1)];
+                            bb = p.ktailB[e_file * p.s_ktailB + min(ca + 32, e_n - 1)];
                         }
                         e0.finish(p, e_file, row_w, tr, hh, ca, ba, bb, s_rowvec, acc[0][0], acc[0][1], oka, okb, cb);
                         if (trace_row && tid == 0) trace_row[5] = __builtin_amdgcn_s_memrealtime();
@@ -1027,9 +1077,11 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
                     }
                 }
                 if (!lean) {
+                    GemmArgs pq = p;              // (the generic epilogues read the column count from the arguments: the file's own in a ragged batch)
+                    pq.N = e_n;
 #pragma unroll
                     for (int m = 0; m < TM; ++m)
-                        gemm_epilogue_pair<EPI>(p, e_file, row_w + m * 32 + 4 * hh, e_col0 + wn * 64 + l31, acc[m][0], acc[m][1], !NARROW || e_nw == 2);
+                        gemm_epilogue_pair<EPI>(pq, e_file, row_w + m * 32 + 4 * hh, e_col0 + wn * 64 + l31, acc[m][0], acc[m][1], !NARROW || e_nw == 2);
                 }
             }
             if (TAIL) {
@@ -1039,7 +1091,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
                     if (tid < (NARROW && e_nw == 1 ? 32 : BN)) {
                         const float s = (scratch[tid] + scratch[BN + tid]) + (scratch[2 * BN + tid] + scratch[3 * BN + tid]);
                         const int col = e_col0 + tid;
-                        if (gemm_col_valid<EPI>(p, col)) gemm_epilogue<EPI>(p, e_file, p.tail_row, col, s);
+                        if (EPI == EPI_PHASE ? gemm_col_valid<EPI>(p, col) : col < e_n) gemm_epilogue<EPI>(p, e_file, p.tail_row, col, s);
                     }
                 }
             }
@@ -1049,7 +1101,7 @@ __device__ __forceinline__ void gemm_dma_workgroup(const GemmArgs& p, float* con
                     s += __shfl_xor(s, 1);
                     s += __shfl_xor(s, 2);
                     const int j = tid >> 2;
-                    if ((tid & 3) == 0 && (e_col0 + j) < p.N && (!NARROW || e_nw == 2 || j < 32)) p.rowsumB[e_file * p.s_rowsumB + e_col0 + j] = s;
+                    if ((tid & 3) == 0 && (e_col0 + j) < e_n && (!NARROW || e_nw == 2 || j < 32)) p.rowsumB[e_file * p.s_rowsumB + e_col0 + j] = s;
                 }
             }
         }
@@ -1147,6 +1199,7 @@ static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM, bool whole_fi
     a.lists = (a.xcd_affine && a.batch >= 8) ? 8 : 1;
     const int policy = gccnmf_tune_tail_split;
     const bool narrow_ok = narrow_capable && TM == 4 && policy != 0;
+    a.narrow_ok = narrow_ok ? 1 : 0;
     const long tiles = (long)a.batch * a.tiles_m * a.tiles_n;
     if (tiles > (1L << 28)) return -1;
     a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;

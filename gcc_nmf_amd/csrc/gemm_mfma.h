@@ -51,6 +51,8 @@ enum GemmEpilogue {
     EPI_UPDW = 4     // block-level: W = normalise(W * acc / rowsum(B)); the tile must own every row  (:77,:79-80)
 };
 
+#define GEMM_RAGGED_LMAX 31      // files per XCD list of a ragged launch
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -96,6 +98,11 @@ struct GemmArgs {
     int split;                 // the last `split` wide tiles of every list run as two narrow (512 x 32) halves
     int rag, wide_n;           // rag = 1: the last column tile of a file is a narrow item; wide_n = tiles_n - rag
     int whole_files;           // chained launches: list x holds WHOLE files (x, x + 8, ...), each file's items together, its ragged items (rag) behind its wide tiles
+    // ragged batches (files of different lengths in one chained launch; gccnmf_klnmf_ragged): device tables
+    const int* ragged_n;       // [file] this GEMM's ragged extent of the file: its output COLUMNS (K1 - K3: N_f), or -- ragged_kd -- its REDUCTION length (K4: N_f)
+    const int* ragged_lists;   // [8][GEMM_RAGGED_LMAX + 1]: per list the number of files, then their indexes in list order
+    int ragged_kd;
+    int narrow_ok;             // the instantiation carries the narrow loop and the tuning allows narrow items: a file's ragged last column tile is one
     int wpl, prefetch;         // persistent grid: resident workgroups per list; 1 = the next item's first k-tile is requested before the epilogue
     unsigned* tickets;         // persistent grid: [0..7] next-item counters per list, [8] workgroups gone; nullptr = classic grid
     int trace_rows, trace_grid;   // rows of the trace buffer; items of the classic grid (the per-wave probe rows start behind them)

@@ -19,7 +19,10 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);       // the LDS-
 #include "../../include/gccnmf_hip.h"
 
 #include <atomic>
+#include <algorithm>
+#include <vector>
 #define GCCNMF_SHARED_STREAMS 4
+#define GCCNMF_RAGGED_MAX_BATCH 248   // files of a ragged batch: 8 lists of at most GEMM_RAGGED_LMAX
 #define GCCNMF_SPLITS 4           // parts of the round-3 single-file split-K (experiment builds); the workspace layout keeps room for them
 #define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
                                      // the ring / throughput kernels win anyway: 8 files 41.5 against 41.3 ms, 12 files 61.9 against 59.3)
@@ -53,7 +56,6 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
                                         //    2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call
     {0, 0, 1, 1},                       // 22 chain_solo: chained launches with one workgroup per CU (the freedom-from-deadlock test)
     {1, 0, 1, 0},                       // 23 chain_rag: chained launches on whole-file lists (0: the plain launch's lists, batch a multiple of 8 only)
-    {0, 0, 1, 0},                       // 24 chain_local: ready counters through the XCD's L2 only (1) or agent scope (0)
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
 static std::atomic<int> gccnmf_knobs_ready{0};
@@ -851,30 +853,51 @@ static long klnmf_workspace_base_floats(const NmfGeom& g, int batch) {
 }
 // Which iterations can be chained: the four GEMMs all on full-height LDS-DMA throughput tiles with one XCD-affine list per XCD, every
 // file's tiles on ONE XCD in every stage (batch a multiple of 8: list x holds the files x, x + 8, ... in all four GEMMs).
+static bool chain_capable(const NmfGeom& g, int batch, int flags, bool any_size = false);
+static bool chain_rule(int batch, int flags);
 static int chain_stages(const NmfGeom& g, int batch, int flags) {
     const int want = gccnmf_tune_chain;
-    if (!want || !gccnmf_tune_dma || gccnmf_tune_tile_policy == 2 || gccnmf_tune_tail_split > 1) return 0;
-    if (direct_path(g, batch) || (flags & 3) || batch < 8 || ((batch & 7) && !gccnmf_tune_chain_rag)) return 0;
+    if (!want || !chain_capable(g, batch, flags) || ((batch & 7) && !gccnmf_tune_chain_rag)) return 0;
+    if (gccnmf_tune_tile_policy != 1 && (long)batch * gccnmf_ceil_div(g.N, 64) < 256) return 0;      // (the small-batch tile's territory)
+    if (want != 1) return want;                                   // a forced form
+    return chain_rule(batch, flags) ? 8 : 0;
+}
+// the shape and tuning conditions of any chained launch: the four GEMMs all on full-height LDS-DMA throughput tiles (K2 half-height up to 256 atoms)
+// with one XCD-affine list per XCD
+static bool chain_capable(const NmfGeom& g, int batch, int flags, bool any_size) {
+    if (!gccnmf_tune_dma || gccnmf_tune_tile_policy == 2 || gccnmf_tune_tail_split > 1) return false;
+    if (direct_path(g, batch) || (flags & 3) || batch < 8) return false;
     // (K a multiple of 128: a K2 tile whose last wave is partly beyond M takes the generic epilogue h * (acc / den) for that wave, a plain
     // launch on half-height tiles the lean one (h * acc) * (s / den) for the same rows: a few ulp apart, so the forms would not be bitwise equal)
-    if (g.K <= 128 || g.Fm <= 128 || g.Fm > 512 || (g.Fm & 127) || (g.K & 127) || (g.F % 16) != 1 || !g.tail) return 0;
-    if (gccnmf_tune_tile_policy != 1 && (long)batch * gccnmf_ceil_div(g.N, 64) < 256) return 0;      // (the small-batch tile's territory)
-    if (!can_fuse_w_update(g, batch)) return 0;
-    if (want != 1) return want;                                   // a forced form
+    if (g.K <= 128 || g.Fm <= 128 || g.Fm > 512 || (g.Fm & 127) || (g.K & 127) || (g.F % 16) != 1 || !g.tail) return false;
+    // (a plain launch of a few files takes the two-launch W update -- other kernels, other summation order; a ragged batch has no plain form to agree with)
+    return any_size || can_fuse_w_update(g, batch);
+}
+static bool chain_rule(int batch, int flags) {
     // The rule (profiles/r06h_files_sweep_*.txt, one-stream iteration as a fraction of the f32 peak, plain launches -> whole-call chain):
     //   24 files 0.74 -> 0.78, 32: 0.81 -> 0.85, 40: 0.73 -> 0.86, 64: 0.83 -> 0.86, 72: 0.79 -> 0.86, 104: 0.80 -> 0.86 -- but 16 files (two per XCD:
     //   the four stages of so few files cannot fill 64 slots): 0.75 -> 0.59, and with whole-file lists the longest list sets the pace: 25
     //   files (4 on one XCD, 3 on the others) 0.77 -> 0.68, 51: a tie, 52 (7 | 6): 0.75 -> 0.80.  So: at least three files per XCD and a longest
     //   list at most 8 % above the mean.  Not beside another file group's launches (flag bit 2): two chained launches that share the chip
     //   are slower than two plain ones (155 k against 158 k frames/s end to end).
-    if (flags & 4) return 0;
+    if (flags & 4) return false;
     const int longest = (batch + 7) / 8;
-    if (batch < 24 || 100L * 8 * longest > 108L * batch) return 0;
-    return 8;
+    return batch >= 24 && 100L * 8 * longest <= 108L * batch;
 }
 
+// A ragged batch (gccnmf_klnmf_ragged): files of different lengths in ONE chained launch.  g is the geometry of the LONGEST file (every file's V, H,
+// R live in blocks of that pitch); n[f] = the file's own column count.  The host deals the files out to the eight XCD lists (longest first, each to
+// the list with the least work so far); the device tables sit behind the counters in the workspace.
+struct RaggedPlan {
+    const int* n;                                   // host [batch]
+    int lists[8][GEMM_RAGGED_LMAX + 1];             // host: count, files
+    const int* d_n;                                 // device copies
+    const int* d_lists;
+};
+
 static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, float* W, float* H, float* R, float* colsumW, float* hscale,
-                              float alpha, float eps, int batch, int flags, unsigned* counters, int it0, int iterations, hipStream_t s) {
+                              float alpha, float eps, int batch, int flags, unsigned* counters, int it0, int iterations, hipStream_t s,
+                              const RaggedPlan* rg = nullptr) {
     GemmArgs a[4] = {};
     const int concurrent = (flags & 4) ? 1 : 0;
     for (int i = 0; i < 4; ++i) {
@@ -914,8 +937,22 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
         if (i < stages) {
             // whole-file lists (key 23, default): any batch size, K4 never waits for a ragged K3 item at the end of a list
             const int tm = (i == 1 && tm1 == 2) ? 2 : 4;
-            const int grid = gemm_dma_plan(a[i], i != 3 && tm == 4, tm, gccnmf_tune_chain_rag != 0);
+            int grid = gemm_dma_plan(a[i], i != 3 && tm == 4, tm, gccnmf_tune_chain_rag != 0 || rg != nullptr);
             if (grid < 8 || a[i].lists != 8 || a[i].split) return GCCNMF_ERR_ARG;
+            if (rg) {
+                // per list: the sum over its files of tiles_m x the file's own column tiles (K4: the uniform atom tiles, the file's own reduction length)
+                a[i].ragged_n = rg->d_n; a[i].ragged_lists = rg->d_lists; a[i].ragged_kd = i == 3 ? 1 : 0;
+                long longest = 0;
+                for (int l = 0; l < 8; ++l) {
+                    long items = 0;
+                    for (int k = 0; k < rg->lists[l][0]; ++k)
+                        items += (long)a[i].tiles_m * (i == 3 ? a[i].tiles_n : gccnmf_ceil_div(rg->n[rg->lists[l][1 + k]], 64));
+                    if (items > longest) longest = items;
+                }
+                if (longest < 1 || longest > (1L << 24)) return GCCNMF_ERR_ARG;
+                a[i].cw = (int)longest;
+                grid = 8 * a[i].cw;
+            }
             len = grid / 8;
         }
         ch.first[i + 1] = ch.first[i] + len;
@@ -928,25 +965,28 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     unsigned* err = c41 + batch;
     for (int i = 0; i < 4; ++i) {
         ch.sync[i].error = err;
-        ch.sync[i].last_tile = tn - 1;
+        ch.sync[i].xcc_seen = err + 16;
     }
+    // does a producer run a file's ragged last column tile as ONE narrow item?  (a uniform batch: decided for the launch; a ragged one: per file)
+    auto narrow_items = [&](int i) { return rg ? a[i].narrow_ok : (a[i].rag ? 1 : 0); };
     // K1 -> K2: column tile j of a file is ready when its 32-column blocks (2; the ragged last tile as ONE narrow item: 1) are stored
     ch.sync[0].sig_cnt = c12; ch.sync[0].sig_stride = tn; ch.sync[0].sig_per_tile = 1;
     ch.sync[1].wait_cnt = c12; ch.sync[1].wait_stride = tn; ch.sync[1].wait_per_tile = 1;
-    ch.sync[1].wait_need = 2u; ch.sync[1].wait_need_last = a[0].rag ? 1u : 2u;
+    ch.sync[1].wait_need = 2u; ch.sync[1].prod_narrow = narrow_items(0);
     if (stages == 4) {
         // K2 -> K3: both atom tiles (tiles_m of K2) of column tile j;  K3 -> K4: every item of the file
         ch.sync[1].sig_cnt = c23; ch.sync[1].sig_stride = tn; ch.sync[1].sig_per_tile = 1;
         ch.sync[2].wait_cnt = c23; ch.sync[2].wait_stride = tn; ch.sync[2].wait_per_tile = 1;
-        ch.sync[2].wait_need = 2u * a[1].tiles_m; ch.sync[2].wait_need_last = (a[1].rag ? 1u : 2u) * a[1].tiles_m;
+        ch.sync[2].wait_need = 2u * a[1].tiles_m; ch.sync[2].prod_narrow = narrow_items(1);
         ch.sync[2].sig_cnt = c34; ch.sync[2].sig_stride = 1; ch.sync[2].sig_per_tile = 0;
         ch.sync[3].wait_cnt = c34; ch.sync[3].wait_stride = 1; ch.sync[3].wait_per_tile = 0;
-        ch.sync[3].wait_need = ch.sync[3].wait_need_last = (unsigned)(a[2].tiles_m * a[2].tiles_n);
+        ch.sync[3].wait_need = (unsigned)(a[2].tiles_m * (rg ? 1 : a[2].tiles_n));
+        ch.sync[3].wait_scale_tiles = rg ? 1 : 0;
         if (iterations > 1) {
             // K4 -> the next iteration's K1: every atom tile of the file (W, its column sums and the pending row scale are complete; R is free)
             ch.sync[3].sig_cnt = c41; ch.sync[3].sig_stride = 1; ch.sync[3].sig_per_tile = 0;
             ch.sync[0].wait_cnt = c41; ch.sync[0].wait_stride = 1; ch.sync[0].wait_per_tile = 0; ch.sync[0].wait_lag = 1;
-            ch.sync[0].wait_need = ch.sync[0].wait_need_last = (unsigned)(a[3].tiles_m * a[3].tiles_n);
+            ch.sync[0].wait_need = (unsigned)(a[3].tiles_m * a[3].tiles_n);
         }
     }
     if (iterations > 1 && stages != 4) return GCCNMF_ERR_ARG;
@@ -1132,6 +1172,78 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
         }
     }
     if (chained && iterations > 0) {
+        hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
+        GCCNMF_CHECK_LAUNCH();
+    }
+    return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
+}
+
+// ---- ragged batches: mixtures of different lengths in one call (gccNMF/runGCCNMF.py:30-36 separates a file of ANY length) -------------
+struct RaggedTables {
+    int v[GCCNMF_RAGGED_MAX_BATCH + 8 * (GEMM_RAGGED_LMAX + 1)];
+};
+__global__ void nmf_store_ragged_tables_kernel(RaggedTables t, int* dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = t.v[i];
+}
+static long ragged_table_ints(int batch) { return (long)gccnmf_round_up(batch + 8 * (GEMM_RAGGED_LMAX + 1), 4); }
+
+long gccnmf_klnmf_ragged_workspace_floats(int F, int Nmax, int K, int batch) {
+    GCCNMF_ENTER();
+    if (F < 2 || Nmax < 1 || K < 1 || batch < 1 || batch > GCCNMF_RAGGED_MAX_BATCH) return -1;
+    NmfGeom g = make_geom(F, Nmax, K);
+    return klnmf_workspace_base_floats(g, batch) + chain_counter_floats(g, batch) + ragged_table_ints(batch);
+}
+
+int gccnmf_klnmf_ragged(const float* V, float* W, float* H, float* workspace, int F, const int* N, int Nmax, int K, int batch, int iterations,
+                        float sparsity_alpha, float epsilon, int flags, void* stream) {
+    GCCNMF_ENTER();
+    if (!V || !W || !H || !workspace || !N || F < 2 || Nmax < 1 || K < 1 || batch < 1 || iterations < 0) return GCCNMF_ERR_ARG;
+    if (batch > GCCNMF_RAGGED_MAX_BATCH) return GCCNMF_ERR_UNSUPPORTED;
+    long tiles = 0;
+    for (int f = 0; f < batch; ++f) {
+        if (N[f] < 1 || N[f] > Nmax) return GCCNMF_ERR_ARG;
+        tiles += gccnmf_ceil_div(N[f], 64);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    NmfGeom g = make_geom(F, Nmax, K);
+    // a ragged batch exists only as a chained launch (the plain launches take one N for the whole batch): where that form is not available
+    // -- short dictionaries, a handful of files -- the caller runs the files of each length as a batch of their own
+    if (!gccnmf_tune_chain || !chain_capable(g, batch, flags & ~4, true) || (gccnmf_tune_tile_policy != 1 && tiles < 256)) return GCCNMF_ERR_UNSUPPORTED;
+    // deal the files out to the eight lists: longest first, each to the list with the fewest column tiles so far (ties: the lower list)
+    RaggedPlan rg = {};
+    rg.n = N;
+    std::vector<int> order(batch);
+    for (int f = 0; f < batch; ++f) order[f] = f;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return N[x] > N[y]; });
+    long load[8] = {};
+    for (int f : order) {
+        int best = 0;
+        for (int l = 1; l < 8; ++l)
+            if (load[l] < load[best]) best = l;
+        int& cnt = rg.lists[best][0];
+        if (cnt >= GEMM_RAGGED_LMAX) return GCCNMF_ERR_UNSUPPORTED;
+        rg.lists[best][1 + cnt++] = f;
+        load[best] += gccnmf_ceil_div(N[f], 64);
+    }
+    for (int l = 0; l < 8; ++l) std::sort(rg.lists[l] + 1, rg.lists[l] + 1 + rg.lists[l][0]);      // a list serves its files in ascending order
+    unsigned* counters = (unsigned*)(workspace + klnmf_workspace_base_floats(g, batch));
+    int* tables = (int*)(counters + chain_counter_floats(g, batch));
+    RaggedTables t = {};
+    for (int f = 0; f < batch; ++f) t.v[f] = N[f];
+    for (int l = 0; l < 8; ++l)
+        for (int k = 0; k <= GEMM_RAGGED_LMAX; ++k) t.v[batch + l * (GEMM_RAGGED_LMAX + 1) + k] = rg.lists[l][k];
+    hipLaunchKernelGGL(nmf_store_ragged_tables_kernel, dim3(1), dim3(256), 0, s, t, tables, batch + 8 * (GEMM_RAGGED_LMAX + 1));
+    GCCNMF_CHECK_LAUNCH();
+    rg.d_n = tables;
+    rg.d_lists = tables + batch;
+    int rc;
+    if ((rc = klnmf_stage(0, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
+    if (iterations > 0) {
+        if (hipMemsetAsync(counters, 0, sizeof(unsigned) * chain_counter_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        float* R = workspace;
+        float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;
+        float* hscale = colsumW + 2L * batch * g.Kp;
+        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags & ~4, counters, 0, iterations, s, &rg))) return rc;
         hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
         GCCNMF_CHECK_LAUNCH();
     }

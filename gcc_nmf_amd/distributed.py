@@ -21,10 +21,25 @@ from . import _hip
 from .engine import Geometry, padded, _ptr, _stream, _on_device
 
 
-def shard_files(num_files, world_size, rank):
-    """Contiguous, balanced shard of file indexes for ``rank`` (first ``num_files % world_size`` ranks get one more)."""
+def shard_files(num_files, world_size, rank, frames=None):
+    """File indexes of ``rank``.  Equal-length files (``frames`` None): a contiguous, balanced shard (the first ``num_files % world_size``
+    ranks get one more).  Files of DIFFERENT lengths (``frames`` = the frame count, or any cost, of every file): balanced by frames, not by
+    count -- longest file first, each to the rank with the fewest frames so far (ties: the lower rank; the same deterministic deal on every
+    rank), returned in ascending file order.  With equal ``frames`` this deals round-robin: the counts per rank are those of the contiguous form."""
     if not 0 <= rank < world_size:
         raise ValueError('rank %d outside world of %d' % (rank, world_size))
+    if frames is not None:
+        frames = [int(f) for f in frames]
+        if len(frames) != num_files:
+            raise ValueError('frames must name every file')
+        load = [0] * world_size
+        mine = []
+        for i in sorted(range(num_files), key=lambda i: (-frames[i], i)):
+            r = min(range(world_size), key=lambda r: (load[r], r))
+            load[r] += frames[i]
+            if r == rank:
+                mine.append(i)
+        return sorted(mine)
     q, r = divmod(num_files, world_size)
     start = rank * q + min(rank, r)
     return list(range(start, start + q + (1 if rank < r else 0)))

@@ -90,7 +90,15 @@ def padded(host, shape, device, dtype=torch.float32):
 
 
 class GCCNMFEngine(object):
-    """All buffers of one batch shape, allocated once; ``separate()`` runs the full path on device."""
+    """All buffers of one batch shape, allocated once; ``separate()`` runs the full path on device.
+
+    ``GCCNMFEngine(lengths=[n_0, n_1, ...], ...)`` -- mixtures of DIFFERENT lengths -- returns a ``RaggedGCCNMFEngine``."""
+
+    def __new__(cls, n_samples=None, *args, **kwargs):
+        if cls is GCCNMFEngine and kwargs.get('lengths') is not None:
+            kwargs = dict(kwargs)
+            return RaggedGCCNMFEngine(kwargs.pop('lengths'), *args, **kwargs)
+        return super(GCCNMFEngine, cls).__new__(cls)
 
     def __init__(self, n_samples, sampleRate=16000, windowSize=1024, hopSize=256, numTDOAs=128,
                  microphoneSeparationInMetres=1.0, numTargets=3, dictionarySize=128, numIterations=100,
@@ -471,3 +479,112 @@ class GCCNMFEngine(object):
         g = self.g
         s = torch.view_as_complex(self.spec)[:, :, :g.F, :g.T].cpu().numpy()
         return s.reshape(self.batch, g.S, 2, g.F, g.T)
+
+
+class RaggedGCCNMFEngine(object):
+    """A batch of mixtures of DIFFERENT lengths (the reference separates a file of any length per call, gccNMF/runGCCNMF.py:30-36; sharding
+    "independent mixture files" over GPUs means files as they come).  ``lengths``: samples per file, in the caller's order.
+
+    KL-NMF -- 98 % of the path -- runs over ALL files in ONE chained launch whose work lists hold each file's own column tiles
+    (gccnmf_klnmf_ragged: padding to the 64-column tile only, the files dealt out to the XCDs by length).  The one-shot stages (STFT,
+    localisation, masks, reconstruction, iSTFT) run per distinct length, on the ordinary engine of that length.  A file's results are bit
+    for bit those it gets in an equal-length batch.  Where the library has no chained form for the shape (GCCNMF_ERR_UNSUPPORTED: short
+    dictionaries, a handful of files) the files of each length run their KL-NMF as a batch of their own."""
+
+    def __init__(self, lengths, sampleRate=16000, windowSize=1024, hopSize=256, numTDOAs=128, microphoneSeparationInMetres=1.0,
+                 numTargets=3, dictionarySize=128, numIterations=100, sparsityAlpha=0, epsilon=1e-16, seedValue=0,
+                 windowFunction=np.hanning, device='cuda:0', klnmf_flags=0):
+        if not torch.cuda.is_available():
+            raise _hip.HipLibraryError('no ROCm device visible: the GCC-NMF HIP path has no CPU fallback')
+        self.lib = _hip.lib()
+        self.device = torch.device(device)
+        self.lengths = [int(n) for n in lengths]
+        if not self.lengths:
+            raise ValueError('no files')
+        self.batch = len(self.lengths)
+        self.iters, self.alpha, self.eps = int(numIterations), float(sparsityAlpha), float(epsilon)
+        self.klnmf_flags = klnmf_flags
+        kw = dict(sampleRate=sampleRate, windowSize=windowSize, hopSize=hopSize, numTDOAs=numTDOAs,
+                  microphoneSeparationInMetres=microphoneSeparationInMetres, numTargets=numTargets, dictionarySize=dictionarySize,
+                  numIterations=numIterations, sparsityAlpha=sparsityAlpha, epsilon=epsilon, seedValue=seedValue,
+                  windowFunction=windowFunction, device=device, klnmf_flags=klnmf_flags)
+        # one ordinary engine per distinct length: its files (caller's indexes, ascending) are its batch
+        self.files_of = {}
+        for i, n in enumerate(self.lengths):
+            self.files_of.setdefault(n, []).append(i)
+        self.sub = dict((n, GCCNMFEngine(n, batch=len(idx), nmf_groups=1, **kw)) for n, idx in sorted(self.files_of.items()))
+        longest = self.sub[max(self.sub)]
+        self.g = g = longest.g                                   # geometry of the longest file: the pitch of every file's V / H block
+        self.N = [self.sub[n].g.N for n in self.lengths]       # columns per file
+        self.frames = [self.sub[n].g.T for n in self.lengths]
+        with torch.cuda.device(self.device):
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+            self.ragged = None
+            if len(self.sub) > 1:
+                import ctypes
+                ws = self.lib.gccnmf_klnmf_ragged_workspace_floats(g.F, g.N, g.K, self.batch)
+                if ws > 0:
+                    self.ragged = dict(V=z(self.batch, g.Fp, g.Np), W=z(self.batch, g.Fp, g.Kp), H=z(self.batch, g.Kp, g.Np), ws=z(ws),
+                                       N=(ctypes.c_int * self.batch)(*self.N))
+        self.ragged_klnmf_used = None                            # set by run(): True = one ragged launch, False = one call per length
+
+    def klnmf(self):
+        """KL-NMF of every file: one ragged chained launch, or -- where the library has none for this shape -- one call per length."""
+        with torch.cuda.device(self.device):
+            r = self.ragged
+            if r is not None:
+                g = self.g
+                for n, e in self.sub.items():
+                    idx = torch.as_tensor(self.files_of[n], device=self.device)
+                    r['V'][idx, :, :e.g.Np] = e.V                # (columns beyond a file's own stay zero: never written)
+                    r['W'][idx] = e.W0
+                    r['H'][idx, :, :e.g.Np] = e.H0
+                rc = self.lib.gccnmf_klnmf_ragged(_ptr(r['V']), _ptr(r['W']), _ptr(r['H']), _ptr(r['ws']), g.F, r['N'], g.N, g.K, self.batch,
+                                                  self.iters, self.alpha, self.eps, self.klnmf_flags, _stream())
+                if rc == 0:
+                    for n, e in self.sub.items():
+                        idx = torch.as_tensor(self.files_of[n], device=self.device)
+                        e.W.copy_(r['W'][idx])
+                        e.H.copy_(r['H'][idx, :, :e.g.Np])
+                    self.ragged_klnmf_used = True
+                    return
+                if rc != 3:                                      # GCCNMF_ERR_UNSUPPORTED: no chained form for this shape
+                    _hip.check(rc, 'gccnmf_klnmf_ragged')
+            self.ragged_klnmf_used = False
+            for e in self.sub.values():
+                e.klnmf()
+
+    def run(self, stft=True):
+        if stft:
+            for e in self.sub.values():
+                e.stft()
+        self.klnmf()
+        for e in self.sub.values():
+            e.localize()
+            e.masks()
+            e.reconstruct()
+            e.istft()
+
+    def upload(self, mixtures):
+        """mixtures[i]: (2, lengths[i]) float32 samples of file i."""
+        if len(mixtures) != self.batch:
+            raise ValueError('expected %d mixtures' % self.batch)
+        for n, e in self.sub.items():
+            e.upload(np.stack([np.asarray(mixtures[i], dtype=np.float32) for i in self.files_of[n]]))
+
+    def separate(self, mixtures):
+        """list of (2, lengths[i]) float32 host arrays -> list of (S, 2, hop * (T_i - 1)) float32 host waveforms, in the caller's order."""
+        self.upload(mixtures)
+        self.run()
+        out = [None] * self.batch
+        for n, e in self.sub.items():
+            y = e.y.cpu().numpy()
+            e.check_status()
+            for k, i in enumerate(self.files_of[n]):
+                out[i] = y[k]
+        return out
+
+    def file(self, i):
+        """(engine of file i's length, its index in that engine's batch): ``e, k = eng.file(i); e.get_WH()[0][k]``."""
+        n = self.lengths[i]
+        return self.sub[n], self.files_of[n].index(i)

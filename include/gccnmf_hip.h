@@ -67,7 +67,6 @@ int gccnmf_version(void);
  *      per XCD, balanced whole-file lists, no other file group beside it; 0 = never; forced forms for tests and A/B runs: 2 = K1 | K2, 4 = the
  *      four GEMMs of an iteration, 8 = every iteration of the call.  Bitwise the same factors in every form.
  *  23  1 (default) = chained launches on whole-file lists (any batch size); 0 = on the plain launch's lists (batch a multiple of 8)
- *  24  1 = the ready counters of chained launches stay in the XCD's own L2 (default 0: agent scope; measured equal)
  *   X  1 ablations of the register-staged kernel (results INVALID), 4 ring kernel off, 5 / 6 parts of the round-3 single-file split-K, 11 / 13
  *      fixed tile / pipeline depth of the direct kernels, 14 short H updates off the ring kernel, 15 one FFT stage per LDS round trip, 18 / 19
  *      resident-workgroup grid and its prefetch, 20 the 16-atom W update, 22 chained launches with one workgroup per CU
@@ -131,8 +130,21 @@ long gccnmf_klnmf_workspace_floats(int F, int N, int K, int batch);
 int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
                  int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
 
+/* The same for mixtures of DIFFERENT lengths in one call (the reference separates a file of any length, gccNMF/runGCCNMF.py:30-36; a
+ * batch of them shards "independent mixture files" whatever their durations): file b has N[b] <= Nmax columns (N: HOST array of `batch`
+ * ints), every file's V / H block has the pitches of Nmax (gccnmf_pitches(F, Nmax / 2, K)), zero beyond its own columns.  One chained
+ * launch (tuning key 21) whose work lists hold each file's own column tiles -- padding to the 64-column tile only -- dealt out to the
+ * XCDs by length; a file's factors are bit for bit those of gccnmf_klnmf on a batch of files of its length.  GCCNMF_ERR_UNSUPPORTED where
+ * the chained form does not exist (K <= 128 or not a multiple of 128, fewer than 8 files or 256 column tiles, more than 248 files,
+ * F - 1 not a multiple of 128 up to 512): run the files of each length as a batch of their own then.
+ * workspace: gccnmf_klnmf_ragged_workspace_floats(F, Nmax, K, batch). */
+long gccnmf_klnmf_ragged_workspace_floats(int F, int Nmax, int K, int batch);
+int gccnmf_klnmf_ragged(const float* V, float* W, float* H, float* workspace, int F, const int* N, int Nmax, int K, int batch,
+                        int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
+
 /* Which launches gccnmf_klnmf uses for this problem under the current tuning: bit 0 = the direct latency kernels (a handful of files),
- * bit 1 = K1 + K2 as one launch of column tiles (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17).  -1 on bad arguments.
+ * bit 1 = K1 + K2 as one launch of column tiles (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17), bit 3 = the whole
+ * call as one chained launch (key 21).  -1 on bad arguments.
  * (Benchmarks and tests name the kernel they time by this; the result of gccnmf_klnmf does not depend on it beyond round-off.) */
 int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags);
 

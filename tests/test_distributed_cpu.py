@@ -24,6 +24,18 @@ def test_shard_files():
     assert shard_files(64, 8, 3) == list(range(24, 32))
     with pytest.raises(ValueError):
         shard_files(4, 2, 2)
+    # files of different lengths: balanced by frames, every file on exactly one rank, the same deal on every rank
+    rng = np.random.RandomState(3)
+    frames = [int(v) for v in rng.choice([310, 622, 935, 1243], size=61)]
+    for w in (2, 4, 8):
+        shards = [shard_files(61, w, r, frames=frames) for r in range(w)]
+        assert sorted(sum(shards, [])) == list(range(61)) and all(s == sorted(s) for s in shards)
+        loads = [sum(frames[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(frames)                     # greedy longest-first: within one file of each other
+        assert max(loads) <= 1.05 * sum(frames) / w
+    assert [len(shard_files(10, 4, r, frames=[5] * 10)) for r in range(4)] == [3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        shard_files(3, 2, 0, frames=[1, 2])
 
 
 def _problem():

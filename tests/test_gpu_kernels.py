@@ -794,17 +794,13 @@ def test_chained_iteration_is_bitwise_the_four_launches(hip, B, T, K, iters):
             res[chain] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
             if chain:
                 res[(chain, 'again')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
-        # the ready counters through the XCD's own L2 (key 24), and -- batch a multiple of 8 -- on the plain launch's lists (key 23 = 0)
-        assert lib.gccnmf_set_tuning(24, 1) == 0
-        res[(8, 'local')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
-        assert lib.gccnmf_set_tuning(24, 0) == 0
+        # batch a multiple of 8: also on the plain launch's lists (key 23 = 0)
         if B % 8 == 0:
             assert lib.gccnmf_set_tuning(23, 0) == 0 and lib.gccnmf_set_tuning(21, 8) == 0
             res[(8, 'plain lists')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
     finally:
         lib.gccnmf_set_tuning(21, 1)
         lib.gccnmf_set_tuning(23, 1)
-        lib.gccnmf_set_tuning(24, 0)
     W, H = res[0]
     assert torch.isfinite(W).all() and torch.isfinite(H).all()
     for key, (Wc, Hc) in res.items():

@@ -521,3 +521,44 @@ def test_fused_istft_overlap_add_is_bitwise_the_two_kernel_form(n, hop, K, batch
     e.istft(keep_frames=True)
     assert torch.equal(e.y, y_fused)
     assert torch.isfinite(y_fused).all() and y_fused.abs().max() > 0
+
+
+@pytest.mark.parametrize('K,iters,expect_ragged', [(1024, 6, True), (256, 5, True), (128, 8, False)])
+def test_ragged_batch_is_bitwise_the_equal_length_batches(K, iters, expect_ragged):
+    """Mixtures of different lengths in one batch (the reference separates a file of any length, runGCCNMF.py:30-36): 5 s, 10 s and 15 s
+    files interleaved, KL-NMF over all of them in ONE chained launch whose lists hold each file's own column tiles
+    (gccnmf_klnmf_ragged).  Every file gets bit for bit the factors, masks and waveforms it gets in a batch of files of its own length;
+    K = 128 has no chained form -- the engine then runs one KL-NMF call per length, same bits."""
+    from gcc_nmf_amd.engine import GCCNMFEngine, RaggedGCCNMFEngine
+    from gcc_nmf_amd.synthetic import synthetic_mixture
+    lengths = [80000, 160000, 240000] * 8 + [160000]
+    xs = [synthetic_mixture(900 + i, numSamples=n) for i, n in enumerate(lengths)]
+    kw = dict(dictionarySize=K, numIterations=iters)
+    e = GCCNMFEngine(lengths=lengths, **kw)
+    assert isinstance(e, RaggedGCCNMFEngine) and e.batch == 25 and e.frames[:3] == [309, 622, 934]
+    ys = e.separate(xs)
+    assert e.ragged_klnmf_used is expect_ragged
+    assert np.array_equal(e.separate(xs)[7], ys[7])                        # a second run of the same engine reproduces it
+    from gcc_nmf_amd import _hip
+    lib = _hip.lib()
+    for n in sorted(set(lengths)):
+        idx = [i for i, m in enumerate(lengths) if m == n]
+        ref = engine(n, batch=len(idx), **kw)
+        try:
+            # an equal-length batch of 8 or 9 files would by itself take the small-batch kernels (other tiles, other summation order); on the
+            # tiles a batch at scale takes -- the ones the ragged launch runs -- it is bit for bit the same (tuning key 2 = 1: any size on them)
+            assert K <= 128 or lib.gccnmf_set_tuning(2, 1) == 0
+            yr = ref.separate(np.stack([xs[i] for i in idx]))
+        finally:
+            lib.gccnmf_set_tuning(2, 0)
+        sub = e.sub[n]
+        assert torch.equal(sub.W, ref.W) and torch.equal(sub.H, ref.H), n
+        assert torch.isfinite(sub.W).all() and torch.equal(sub.argmax, ref.argmax)
+        for k, i in enumerate(idx):
+            assert ys[i].shape == (3, 2, 256 * (sub.g.T - 1)) and np.array_equal(ys[i], yr[k]), (n, i)
+    # and against the oracle, one file of the shortest length
+    r = O.runGCCNMF(xs[0], 16000, 1024, 256, 128, 1.0, 3, dictionarySize=K, numIterations=iters, return_intermediates=True)
+    sub, k = e.file(0)
+    assert sub.get_tdoa_indexes()[k].tolist() == r['idx']
+    assert rel(sub.get_WH()[0][k], r['W']) < 1e-4 and rel(sub.get_WH()[1][k], r['H']) < 1e-4
+    assert np.sqrt(np.mean((ys[0].astype(np.float64) - r['y']) ** 2)) < 1e-5
