@@ -123,6 +123,9 @@ def _call_with_timeout(fn, seconds, what):
     return box['value']
 
 
+_rccl_given_up = [False]     # a communicator set-up timed out on some rank: the torch route from then on (never a second init beside an orphaned one)
+
+
 def _try_rccl_init(init, seconds, what):
     """(ok, why): init() behind the time limit.  A timeout is NOT raised here: the caller still owes its peers the agreement all-reduce
     (raising first would leave them waiting in it until torch's own timeout), so it comes back as (False, explanation)."""
@@ -143,6 +146,8 @@ def _rccl_comm(group, device):
     if hit is not None and hit[1:] == (world, rank):
         return hit[0]
     lib = _hip.lib()
+    if _rccl_given_up[0]:                             # an earlier set-up timed out somewhere: torch route for the rest of this process (every rank alike)
+        return None
     src = dist.get_global_rank(group, 0) if group is not None else 0
     ident = torch.zeros(_hip.RCCL_UNIQUE_ID_BYTES + 1, dtype=torch.uint8, device=device)     # [id bytes | ok flag]
     if rank == 0 and lib.gccnmf_rccl_available():
@@ -160,10 +165,18 @@ def _rccl_comm(group, device):
         torch.cuda.synchronize(device)
         timeout = float(os.environ.get('GCCNMF_RCCL_INIT_TIMEOUT', '120'))
 
+        abandoned = []                                 # set once the caller has stopped waiting for this init
+
         def init():
             with torch.cuda.device(device):
-                return lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
+                done = lib.gccnmf_rccl_comm_init(ident[:-1].tobytes(), world, rank, ctypes.byref(handle)) == 0
+                if done and abandoned:                     # it came back after the time limit: nobody will ever use this communicator
+                    lib.gccnmf_rccl_comm_destroy(handle)
+                    return False
+                return done
         ok, why = _try_rccl_init(init, timeout, 'gccnmf_rccl_comm_init (rank %d of %d, device %s)' % (rank, world, device))
+        if why:
+            abandoned.append(True)
         # one agreement for both questions: did EVERY rank get a communicator, and did NO rank give up on a timeout
         flag = torch.tensor([1 if ok else 0, 0 if why else 1], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
@@ -178,7 +191,11 @@ def _rccl_comm(group, device):
                           'goes through torch.distributed instead (GCCNMF_COLLECTIVE=torch semantics, same results)'
                           % (why or 'gccnmf_rccl_comm_init failed on this or another rank'), RuntimeWarning)
             if not nobody_timed_out:
-                return None              # a timeout somewhere: not cached on ANY rank, the next training tries RCCL again (all ranks alike)
+                # A timeout somewhere.  The rank that gave up may still have a thread inside ncclCommInitRank (it destroys its communicator
+                # itself should it ever return), and destroying or re-initialising communicators beside it can block: NO rank tries RCCL
+                # again in this process -- the agreement all-reduce made that decision the same on every rank.
+                _rccl_given_up[0] = True
+                return None
     _rccl_comms[key] = (comm, world, rank)
     return comm
 

@@ -425,9 +425,12 @@ def test_klnmf_one_big_matrix_takes_the_column_block_path(hip, N, K, iters):
 
 
 def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
-    """The direct-to-register latency path (csrc/direct.hip) and the round-3 split-K path compute the same factors (different summation
-    grouping: equal to round-off), alone and for a handful of files (tuning key 12 lets small batches take the direct path)."""
+    """The direct-to-register latency path (csrc/direct.hip) against what key 10 = 0 runs for one mixture -- the round-3 split-K launches
+    in the lab build (key 5 exists there), the LDS-DMA ring kernel in the product library, where the split-K path is compiled out -- and for
+    a handful of files (tuning key 12 lets small batches take the direct path): the same factors to round-off (different summation grouping)."""
     lib = hip.lib()
+    lab = lib.gccnmf_set_tuning(5, 3) == 0              # key 5 (parts of the single-file split-K W.H) is an experiment-build key
+    other = 'split' if lab else 'ring'
     F, T, K, B = 513, 311, 256, 3
     g = hip_geometry(F, T, K)
     rng = np.random.RandomState(3)
@@ -435,7 +438,7 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
     from gcc_nmf_amd.engine import klnmf_initial_factors, padded
     W0, H0 = klnmf_initial_factors(F, 2 * T, K)
     res = {}
-    for name, direct, maxb, batch in [('split', 0, 1, 1), ('direct', 1, 1, 1), ('direct-batch', 1, 4, B), ('ring-batch', 0, 1, B)]:
+    for name, direct, maxb, batch in [(other, 0, 1, 1), ('direct', 1, 1, 1), ('direct-batch', 1, 4, B), ('ring-batch', 0, 1, B)]:
         assert lib.gccnmf_set_tuning(10, direct) == 0 and lib.gccnmf_set_tuning(12, maxb) == 0
         Vd = padded(V[:batch], (batch, g.Fp, g.Np), 'cuda')
         Wd = padded(np.repeat(W0[None], batch, 0), (batch, g.Fp, g.Kp), 'cuda')
@@ -448,12 +451,12 @@ def test_klnmf_direct_path_against_the_split_k_path_and_small_batches(hip):
     lib.gccnmf_set_tuning(12, 4)
     for b in range(B):
         Wr, Hr = O.performKLNMF(V[b], K, 7, 0)
-        for name in ('direct-batch', 'ring-batch') + (('split', 'direct') if b == 0 else ()):
+        for name in ('direct-batch', 'ring-batch') + ((other, 'direct') if b == 0 else ()):
             W, H = res[name]
             assert rel(W[b, :F, :K], Wr) < 1e-4 and rel(H[b, :K, :2 * T], Hr) < 1e-4, (name, b)
             # the padding stays exactly zero (it is a reduction operand)
             assert not W[b, F:].any() and not W[b, :, K:].any() and not H[b, K:].any() and not H[b, :, 2 * T:].any(), (name, b)
-    assert rel(res['direct'][0], res['split'][0]) < 2e-5
+    assert rel(res['direct'][0], res[other][0]) < 2e-5
 
 
 @pytest.mark.parametrize('F,T,K,B,alpha', [(513, 75, 128, 6, 0.0), (513, 40, 200, 9, 0.2), (257, 33, 100, 5, 0.0), (385, 20, 64, 12, 0.0),
@@ -857,3 +860,28 @@ def test_chained_launch_completes_with_one_workgroup_per_cu(hip):
         lib.gccnmf_set_tuning(21, 1)
     assert torch.isfinite(W).all() and torch.isfinite(Ws).all()
     assert torch.equal(Ws, W) and torch.equal(Hs, H) and torch.equal(Wc, W) and torch.equal(Hc, H)
+
+
+def test_wide_one_pass_w_update_at_batch_scale(hip):
+    """K <= 128 with at least 256 workgroups of 32 atoms (64 files at K = 128): the W update runs as nmf_update_w_onepass_kernel<32, 1> -- two
+    18-row register sets per thread (190 VGPRs, 2 waves per SIMD, no spill: -Rpass-analysis=kernel-resource-usage), norms and column sums summed in
+    another order than the 16-atom form of smaller batches.  Against the oracle on the first and the last file, and -- lab build, key 20 --
+    against the 16-atom form to round-off."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    B, F, T, K, iters = 64, 513, 40, 128, 6
+    N = 2 * T
+    rng = np.random.RandomState(11)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    W, H = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+    for b in (0, B - 1):
+        Wr, Hr = O.performKLNMF(V[b], K, iters, 0)
+        assert rel(W[b, :F, :K].cpu().numpy(), Wr) < 1e-4 and rel(H[b, :K, :N].cpu().numpy(), Hr) < 1e-4
+    assert torch.allclose(torch.linalg.norm(W[:, :F, :K], dim=1), torch.ones_like(W[:, 0, :K]), atol=1e-5)
+    if lib.gccnmf_set_tuning(20, 0) == 0:                      # experiment build: the 16-atom form at the same batch
+        try:
+            W16, H16 = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        finally:
+            lib.gccnmf_set_tuning(20, 1)
+        assert rel(W.cpu().numpy(), W16.cpu().numpy()) < 1e-5 and rel(H.cpu().numpy(), H16.cpu().numpy()) < 1e-5
