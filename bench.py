@@ -115,10 +115,10 @@ def live_traffic(a, timeout_s=150, chained=False):
     write_kb, _ = res['WRITE_SIZE']
     return ({'hbm_bytes_per_launch': (2.0 * fetch_kb + write_kb) * 1024.0, 'fetch_size_kb_raw': fetch_kb, 'write_size_kb': write_kb,
              'launches': n, 'seconds': time.perf_counter() - t0},
-            'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of bench.py --iterations 10 '
+            'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of bench.py --iterations %d '
             '--nmf-groups 1, mean over %d launches of %s); FETCH_SIZE doubled (gfx950 reports '
             'half of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section), KB = 1024 B'
-            % (n, 'gccnmf_gemm_chain_kernel<true,4> = the whole KL-NMF call, %d iterations x (K1 | K2 | K3 | K4)' % a.iterations if chained
+            % (a.iterations if chained else 10, n, 'gccnmf_gemm_chain_kernel<true,4> = the whole KL-NMF call, %d iterations x (K1 | K2 | K3 | K4)' % a.iterations if chained
                else 'gccnmf_gemm_dma_kernel<true,false,1,...> = K1 + K3'))
 
 
