@@ -54,3 +54,33 @@ int gccnmf_whdiv_rht_launch(WhdivRhtArgs a, hipStream_t stream);
 // out[c][r] = in[r][c] for r < rows, c < cols (batched; strides in floats) -- the transposed copies the direct path starts from
 int gccnmf_transpose_launch(const float* in, long s_in, int ld_in, float* out, long s_out, int ld_out, int rows, int cols, int batch,
                             hipStream_t stream);
+
+
+// ---- the short-dictionary iteration as ONE chained launch (round 6) --------------------------------------------------------------
+// K1 + K2 (column tiles) | K3 + K4a (bin slabs) | the one-pass W update of EVERY iteration of a gccnmf_klnmf call in one kernel: per XCD
+// the items of list x = files x, x + 8, ... whole, stage by stage, iteration by iteration; the stages hand over per FILE through ready
+// counters (chain_sync.h): a slab needs all column tiles of its file, a W-update group all slabs, the next iteration's column tiles
+// all W-update groups.  Same item programs as the three plain launches: same bits.
+struct UpdateWArgs {
+    float* W;
+    const float *U, *rowsumH;
+    float *colsumW, *hscale;
+    int F, K, Kp;
+    long sW, sU, sVec, sRowsum;
+};
+struct ShortChainArgs {
+    WhUpdhArgs a12;
+    WhdivRhtArgs a34;
+    UpdateWArgs aw;
+    int per_file[3];             // items per file of the three stages: column tiles, slabs, atom groups
+    int first[4];                // per list: stage s of an iteration serves positions [first[s], first[s + 1]) -- stage-major, whole files (a
+                                 // two-group order with the groups half an iteration apart, one group's slabs beside the other's column tiles, was
+                                 // measured slower: 0.382 against 0.376 ms per iteration at K = 128, LABBOOK R6.4)
+    int it0, iterations, atoms_per_group, solo;
+    unsigned* counters;          // [3][batch] ready counters (zeroed by the caller), then the error flag / XCC table block of the throughput chain
+    unsigned* error;
+    unsigned* xcc_seen;
+    long long* trace;
+    int trace_rows, trace_it;
+};
+int gccnmf_short_chain_launch(ShortChainArgs a, hipStream_t stream);

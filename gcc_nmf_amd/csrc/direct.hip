@@ -640,19 +640,18 @@ __device__ __forceinline__ float direct_div_fast(float v, float d) {      // v /
     return fmaf(fmaf(-d, q, v), r, q);
 }
 
+// LDS of one workgroup: two W chunks, the tail bin's W row, the tail bin's quotients
 template <int KB>
-__global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs p) {
+struct WhUpdhLds {
+    static constexpr int FLOATS = 2 * 64 * 129 + 32 * KB + 64;
+};
+// One work item: column tile tn of file `file`.  trace: this item's 8-slot timeline row, or nullptr.
+template <int KB>
+__device__ __forceinline__ void gccnmf_wh_updh_item(const WhUpdhArgs& p, const int file, const int tn, float* const smem, long long* const trace) {
     constexpr int PW = 129, NT = 16 * KB, NK = 32 * KB;          // LDS pitch | MFMA steps of the first product | padded atoms
-    __shared__ float Ws[2][64][PW];
-    __shared__ float s_wm[NK], s_r[64];
-    const int tiles = p.tiles_n;
-    int idx = blockIdx.x;
-    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major tile list (blocks b, b + 8, ... run on XCD b % 8)
-        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
-        if (idx >= p.batch * tiles) return;
-    }
-    const int file = __builtin_amdgcn_readfirstlane(idx / tiles);
-    const int tn = __builtin_amdgcn_readfirstlane(idx - file * tiles);
+    float (*Ws)[64][PW] = (float (*)[64][PW])smem;               // [2][64][PW]
+    float* const s_wm = smem + 2 * 64 * PW;                      // [NK]
+    float* const s_r = s_wm + NK;                                // [64]
     const int col0 = tn * 64;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -663,9 +662,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs
     const float* __restrict__ sc = p.scale + file * p.sVec;
     const int nchunks = p.M >> 6;
     const int n = col0 + 32 * nh + l31;                          // this lane's frame
-    if (p.trace && tid == 0) {
-        p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
-        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    if (trace && tid == 0) {
+        trace[0] = __builtin_amdgcn_s_memrealtime();
+        trace[4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
     }
     // staging: the chunk is 64 rows x 8 KB float4; thread tid moves float4 q = tid + 256 i (row q / (8 KB), atoms 4 (q % (8 KB)) ..), i < 2 KB,
     // in two parts of KB float4 each; row (bin) b goes to LDS row slot(b)
@@ -777,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs
             for (int t = 0; t < 8; ++t) av[t] = arow0[(cur ^ 1) * 64 * PW + t];
         }
     }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (trace && tid == 0) trace[2] = __builtin_amdgcn_s_memrealtime();
     // The two bin groups of a frame half meet in LDS (the W chunks are done): fg = 1 hands its part over, fg = 0 adds it to its own, applies
     // the tail bin's rank-1 term, the pending scale and the denominator, and rewrites H.  What that step needs from global memory (the old H
     // values: four consecutive frames per lane and step) is requested before the exchange.
@@ -821,8 +820,23 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs
             }
         }
     }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    if (trace && tid == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
 }
+
+template <int KB>
+__global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[WhUpdhLds<KB>::FLOATS];
+    const int tiles = p.tiles_n;
+    int idx = blockIdx.x;
+    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major tile list (blocks b, b + 8, ... run on XCD b % 8)
+        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
+        if (idx >= p.batch * tiles) return;
+    }
+    const int file = __builtin_amdgcn_readfirstlane(idx / tiles);
+    const int tn = __builtin_amdgcn_readfirstlane(idx - file * tiles);
+    gccnmf_wh_updh_item<KB>(p, file, tn, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr);
+}
+
 
 int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream) {
     if (!a.W || !a.H || !a.V || !a.colsum || !a.scale || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
@@ -858,19 +872,18 @@ int gccnmf_wh_updh_launch(WhUpdhArgs a, hipStream_t stream) {
 // the tile's frames (16 frames per wave, the atoms dealt over 4 lane groups) and accumulates U[M][k] and rowsumH[k] for ITS OWN 16 atoms
 // -- no reduction across workgroups, no extra launch (needs 16 x slabs >= atoms).
 // 64 files x 8 slabs = 512 workgroups: exactly two per CU, one launch instead of two, no 2.7 MB R round trip per file.
+// LDS of one workgroup: two H tiles, the tail bin's W row, the tail sums
 template <int KB>
-__global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRhtArgs p) {
+struct WhdivRhtLds {
+    static constexpr int FLOATS = 2 * 32 * KB * 68 + 32 * KB + 4 * 4 * 4 * 2;
+};
+// One work item: slab sl (64 bins) of file `file`.
+template <int KB>
+__device__ __forceinline__ void gccnmf_whdiv_rht_item(const WhdivRhtArgs& p, const int file, const int sl, float* const smem, long long* const trace) {
     constexpr int P = 68, NCH = 2 * KB, KR = 32 * KB;             // LDS pitch | chunks of 16 atoms | atom rows of the H tile
-    __shared__ __attribute__((aligned(16))) float Hs[2][KR][P];
-    __shared__ float s_w[KR], s_tail[4][4][4][2];
-    const int per_file = p.nslabs;
-    int idx = blockIdx.x;
-    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major workgroup list
-        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
-        if (idx >= p.batch * per_file) return;
-    }
-    const int file = __builtin_amdgcn_readfirstlane(idx / per_file);
-    const int sl = __builtin_amdgcn_readfirstlane(idx - file * per_file);
+    float (*Hs)[KR][P] = (float (*)[KR][P])smem;                  // [2][KR][P] (16-byte aligned: smem is, P is a multiple of 4)
+    float* const s_w = smem + 2 * KR * P;                         // [KR]
+    float (*s_tail)[4][4][2] = (float (*)[4][4][2])(s_w + KR);    // [4][4][4][2]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ W = p.W + file * p.sW;
@@ -890,9 +903,9 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
 #pragma unroll
         for (int i = 0; i < KB; ++i) *(df32x4*)&Hs[buf][(tid >> 4) + 16 * (part * KB + i)][4 * (tid & 15)] = r[i];
     };
-    if (p.trace && tid == 0) {
-        p.trace[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
-        p.trace[8 * blockIdx.x + 4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
+    if (trace && tid == 0) {
+        trace[0] = __builtin_amdgcn_s_memrealtime();
+        trace[4] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 16 | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu));
     }
     df32x4 h0[KB], h1[KB];
     stage_load(h0, 0, 0);
@@ -1033,12 +1046,12 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
             for (int t = 0; t < 8; ++t) av[t] = Hs[cur ^ 1][8 * hh + t][32 * nh + l31];
         }
     }
-    if (p.trace && tid == 0) {
-        p.trace[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
-        p.trace[8 * blockIdx.x + 1] = tt1;
-        p.trace[8 * blockIdx.x + 5] = tt5;
-        p.trace[8 * blockIdx.x + 6] = tt6;
-        p.trace[8 * blockIdx.x + 7] = tt7;
+    if (trace && tid == 0) {
+        trace[2] = __builtin_amdgcn_s_memrealtime();
+        trace[1] = tt1;
+        trace[5] = tt5;
+        trace[6] = tt6;
+        trace[7] = tt7;
     }
     // the two frame halves of a bin group meet in LDS (the H tiles are done): nh = 1 writes, nh = 0 adds and stores U[f][atoms]
 #pragma unroll
@@ -1081,8 +1094,23 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
                 if (atom < p.ldu) *(df32x4*)(U + (long)f * p.ldu + atom) = o;
             }
     }
-    if (p.trace && tid == 0) p.trace[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    if (trace && tid == 0) trace[3] = __builtin_amdgcn_s_memrealtime();
 }
+
+template <int KB>
+__global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRhtArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[WhdivRhtLds<KB>::FLOATS];
+    const int per_file = p.nslabs;
+    int idx = blockIdx.x;
+    if (p.xc) {          // XCD x owns a contiguous eighth of the file-major workgroup list
+        idx = (blockIdx.x & 7) * p.xc + (blockIdx.x >> 3);
+        if (idx >= p.batch * per_file) return;
+    }
+    const int file = __builtin_amdgcn_readfirstlane(idx / per_file);
+    const int sl = __builtin_amdgcn_readfirstlane(idx - file * per_file);
+    gccnmf_whdiv_rht_item<KB>(p, file, sl, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr);
+}
+
 
 int gccnmf_whdiv_rht_launch(WhdivRhtArgs a, hipStream_t stream) {
     if (!a.W || !a.H || !a.V || !a.U || !a.rowsumH || a.batch < 1 || a.N < 1) return GCCNMF_ERR_ARG;
@@ -1103,6 +1131,91 @@ int gccnmf_whdiv_rht_launch(WhdivRhtArgs a, hipStream_t stream) {
     else if (kb == 2) hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<2>, dim3(grid), dim3(256), 0, stream, a);
     else if (kb == 3) hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<3>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(gccnmf_whdiv_rht_kernel<4>, dim3(grid), dim3(256), 0, stream, a);
+    GCCNMF_CHECK_LAUNCH();
+    return GCCNMF_OK;
+}
+
+// ---- the short-dictionary iteration as ONE chained launch (direct.h: ShortChainArgs) ----------------------------------------------------
+#include "chain_sync.h"
+#include "update_w.h"
+
+template <int KB, int AT>
+__global__ __launch_bounds__(256, 2) void gccnmf_short_chain_kernel(const ShortChainArgs c) {
+    constexpr int LDS12 = WhUpdhLds<KB>::FLOATS, LDS34 = WhdivRhtLds<KB>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[LDS12 > LDS34 ? LDS12 : LDS34];
+    static_assert(5 * AT <= LDS12, "");
+    const int list = (int)(blockIdx.x & 7);
+    int pos = (int)(blockIdx.x >> 3), it = c.it0;
+    if (c.iterations > 1) {
+        const int q = pos / c.first[3];
+        it += q;
+        pos -= q * c.first[3];
+    }
+    const int stage = pos < c.first[1] ? 0 : pos < c.first[2] ? 1 : 2;
+    const int r = pos - c.first[stage];
+    const int per = c.per_file[stage];
+    const int ql = r / per, sub = __builtin_amdgcn_readfirstlane(r - ql * per);
+    const int file = __builtin_amdgcn_readfirstlane(list + 8 * ql);
+    const int batch = c.a12.batch;
+    if (file >= batch) return;
+    const int tid = threadIdx.x;
+    long long* const tr = (c.trace && it == c.trace_it && 8 * pos + list < c.trace_rows) ? c.trace + 8 * (long)(8 * pos + list) : nullptr;
+    // stage s waits for the per-file counter of stage s - 1 (stage 0: for the W update of the PREVIOUS iteration) and signals its own
+    GemmSync y = {};
+    y.error = c.error;
+    y.xcc_seen = c.xcc_seen;
+    y.sig_cnt = c.counters + stage * batch;
+    y.sig_stride = 1;
+    y.wait_stride = 1;
+    if (stage > 0 || it > 0) {
+        y.wait_cnt = c.counters + ((stage + 2) % 3) * batch;
+        y.wait_need = (unsigned)c.per_file[(stage + 2) % 3];
+        y.wait_lag = stage == 0 ? 1 : 0;
+    }
+    if (tr && tid == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
+    gemm_sync_wait(y, file, 0, tid, it, list, 0);
+    if (stage == 0) {
+        gccnmf_wh_updh_item<KB>(c.a12, file, sub, smem, tr);
+    } else if (stage == 1) {
+        gccnmf_whdiv_rht_item<KB>(c.a34, file, sub, smem, tr);
+    } else {
+        if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+        nmf_update_w_onepass_item<AT, 1>(c.aw.W, c.aw.U, c.aw.rowsumH, c.aw.colsumW, c.aw.hscale, c.aw.F, c.aw.K, c.aw.Kp, c.aw.sW, c.aw.sU, c.aw.sVec,
+                                         c.aw.sRowsum, 0, 0, nullptr, 0, 0, file, sub, smem);
+        if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    gemm_sync_signal(y, file, 0, 1, tid);
+}
+
+int gccnmf_short_chain_launch(ShortChainArgs a, hipStream_t stream) {
+    if (!a.counters || !a.error || a.iterations < 1 || a.a12.batch < 8) return GCCNMF_ERR_ARG;
+    if (a.a12.M < 64 || a.a12.M > 512 || (a.a12.M & 63) || a.a12.Kd < 1 || a.a12.Kd > 128) return GCCNMF_ERR_UNSUPPORTED;
+    a.a12.tiles_n = gccnmf_ceil_div(a.a12.N, 64);
+    a.a12.xc = 0; a.a12.trace = nullptr;
+    a.a34.nslabs = a.a34.M / 64;
+    a.a34.xc = 0; a.a34.trace = nullptr;
+    if (16 * a.a34.nslabs < 32 * gccnmf_ceil_div(a.a34.Kd, 32)) return GCCNMF_ERR_UNSUPPORTED;
+    if (a.atoms_per_group != 16 && a.atoms_per_group != 32) return GCCNMF_ERR_ARG;
+    a.per_file[0] = a.a12.tiles_n;
+    a.per_file[1] = a.a34.nslabs;
+    a.per_file[2] = a.aw.Kp / a.atoms_per_group;
+    const int longest = (a.a12.batch + 7) / 8;
+    a.first[0] = 0;
+    for (int i = 0; i < 3; ++i) a.first[i + 1] = a.first[i] + longest * a.per_file[i];
+    if ((long)8 * a.first[3] * a.iterations > (1L << 30) || a.it0 != 0) return GCCNMF_ERR_ARG;
+    a.trace = gccnmf_trace_buf;
+    a.trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks : 0;
+    a.trace_it = a.it0 + a.iterations - 1;
+    const int grid = 8 * a.first[3] * a.iterations;
+    const unsigned pad = a.solo ? 24576u : 0u;                     // (lab: one workgroup per CU)
+    const int kb = gccnmf_ceil_div(a.a12.Kd, 32);
+#define GCCNMF_SHORT_CHAIN(KB_, AT_) hipLaunchKernelGGL((gccnmf_short_chain_kernel<KB_, AT_>), dim3(grid), dim3(256), pad, stream, a)
+    if (a.atoms_per_group == 32) {
+        if (kb == 1) GCCNMF_SHORT_CHAIN(1, 32); else if (kb == 2) GCCNMF_SHORT_CHAIN(2, 32); else if (kb == 3) GCCNMF_SHORT_CHAIN(3, 32); else GCCNMF_SHORT_CHAIN(4, 32);
+    } else {
+        if (kb == 1) GCCNMF_SHORT_CHAIN(1, 16); else if (kb == 2) GCCNMF_SHORT_CHAIN(2, 16); else if (kb == 3) GCCNMF_SHORT_CHAIN(3, 16); else GCCNMF_SHORT_CHAIN(4, 16);
+    }
+#undef GCCNMF_SHORT_CHAIN
     GCCNMF_CHECK_LAUNCH();
     return GCCNMF_OK;
 }

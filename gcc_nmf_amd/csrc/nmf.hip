@@ -13,6 +13,7 @@
 #include <mutex>
 #include "gemm_ring.h"
 #include "direct.h"
+#include "update_w.h"
 #ifdef GCCNMF_EXPERIMENTS
 int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);       // the LDS-free throughput tile (direct.hip)
 #endif
@@ -288,97 +289,10 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
                                                                    float* __restrict__ hscale, int F, int K, int Kp, long sW, long sU,
                                                                    long sVec, long sRowsum, long sSplitU, long sSplitR, float* __restrict__ Wt,
                                                                    long sWt, int ldwt) {
-    constexpr int nsplit = NSPLIT;
-    constexpr int L4 = AT / 4;                 // float4 lanes per row segment
-    constexpr int PH = 256 / L4;               // row phases per workgroup (PH / 4 per wave)
-    constexpr int R = (64 * 9 + PH - 1) / PH;  // rows per thread for F <= 576
-    __shared__ float red[4][AT];
-    __shared__ float s_norm[AT];
+    __shared__ __attribute__((aligned(16))) float smem[5 * AT];
     const int chunks = Kp / AT;
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    const int c4 = threadIdx.x % L4, q = threadIdx.x / L4, wave = threadIdx.x >> 6;
-    const int k0 = ch * AT + 4 * c4;
-    const bool v0 = k0 < K, v1 = k0 + 1 < K, v2 = k0 + 2 < K, v3 = k0 + 3 < K;      // padded atoms stay exactly zero
-    float* Wb = W + b * sW;
-    const float* Ub = U + b * sU;
-    float4 rs = *(const float4*)(rowsumH + b * sRowsum + k0);
-#pragma unroll
-    for (int sp = 1; sp < nsplit; ++sp) {
-        const float4 t = *(const float4*)(rowsumH + b * sRowsum + sp * sSplitR + k0);
-        rs.x += t.x; rs.y += t.y; rs.z += t.z; rs.w += t.w;
-    }
-    // every load of the thread is issued before the first use: rows beyond F re-read row F-1 (clamped, always in bounds) and are
-    // masked afterwards -- conditional loads would serialise into R dependent round trips
-    float4 wt[R], uu[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const long i = (long)min(q + PH * r, F - 1) * Kp + k0;
-        wt[r] = *(const float4*)(Wb + i);
-        uu[r] = *(const float4*)(Ub + i);
-    }
-    float4 tt[NSPLIT > 1 ? NSPLIT - 1 : 1][R];          // the partials of a split-K launch: all in flight together, added in ascending order
-#pragma unroll
-    for (int sp = 1; sp < nsplit; ++sp)
-#pragma unroll
-        for (int r = 0; r < R; ++r) tt[sp - 1][r] = *(const float4*)(Ub + sp * sSplitU + (long)min(q + PH * r, F - 1) * Kp + k0);
-#pragma unroll
-    for (int sp = 1; sp < nsplit; ++sp)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uu[r].x += tt[sp - 1][r].x; uu[r].y += tt[sp - 1][r].y; uu[r].z += tt[sp - 1][r].z; uu[r].w += tt[sp - 1][r].w;
-        }
-    float4 ss = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const bool ok = q + PH * r < F;
-        const float4 w = wt[r], u = uu[r];
-        wt[r] = make_float4((ok && v0) ? w.x * (u.x / rs.x) : 0.f, (ok && v1) ? w.y * (u.y / rs.y) : 0.f, (ok && v2) ? w.z * (u.z / rs.z) : 0.f,
-                            (ok && v3) ? w.w * (u.w / rs.w) : 0.f);
-        ss.x = fmaf(wt[r].x, wt[r].x, ss.x);
-        ss.y = fmaf(wt[r].y, wt[r].y, ss.y);
-        ss.z = fmaf(wt[r].z, wt[r].z, ss.z);
-        ss.w = fmaf(wt[r].w, wt[r].w, ss.w);
-    }
-    auto reduce_wave = [&](float4 v) {        // sum over the row phases of this wave (lane bits log2(L4) .. 5)
-#pragma unroll
-        for (int o = L4; o < 64; o <<= 1) {
-            v.x += __shfl_xor(v.x, o);
-            v.y += __shfl_xor(v.y, o);
-            v.z += __shfl_xor(v.z, o);
-            v.w += __shfl_xor(v.w, o);
-        }
-        return v;
-    };
-    ss = reduce_wave(ss);
-    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = ss;
-    __syncthreads();
-    if (threadIdx.x < AT) s_norm[threadIdx.x] = sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
-    __syncthreads();
-    const float4 nm = *(const float4*)&s_norm[4 * c4];
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int f = q + PH * r;
-        if (f < F) {
-            const float4 wn = make_float4(v0 ? wt[r].x / nm.x : 0.f, v1 ? wt[r].y / nm.y : 0.f, v2 ? wt[r].z / nm.z : 0.f,
-                                          v3 ? wt[r].w / nm.w : 0.f);
-            *(float4*)(Wb + (long)f * Kp + k0) = wn;
-            if (Wt) {            // the reduction-major copy the direct path's W.H reads (padded atoms: zero rows)
-                float* t = Wt + b * sWt + (long)k0 * ldwt + f;
-                t[0] = wn.x; t[ldwt] = wn.y; t[2 * (long)ldwt] = wn.z; t[3 * (long)ldwt] = wn.w;
-            }
-            cs.x += wn.x; cs.y += wn.y; cs.z += wn.z; cs.w += wn.w;
-        }
-    }
-    cs = reduce_wave(cs);
-    __syncthreads();
-    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = cs;
-    __syncthreads();
-    if (threadIdx.x < AT && ch * AT + (int)threadIdx.x < K) {
-        const int k = ch * AT + threadIdx.x;
-        colsumW[b * sVec + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        hscale[b * sVec + k] = s_norm[threadIdx.x];
-    }
+    nmf_update_w_onepass_item<AT, NSPLIT>(W, U, rowsumH, colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR, Wt, sWt, ldwt, b, ch, smem);
 }
 
 static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,
@@ -1009,6 +923,43 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     return GCCNMF_OK;
 }
 
+// Short dictionaries (K <= 128): the three launches of an iteration -- K1 + K2 on column tiles, K3 + K4a on bin slabs, the one-pass W update --
+// chained the same way (direct.hip: gccnmf_short_chain_kernel).  Shapes both fused kernels and the one-pass W update take; the same batch
+// rule as the throughput chain.  Returns the atoms per W-update group (16 / 32: what the plain launch would use at this batch), 0 = no chain.
+static int short_chain_group(const NmfGeom& g, int batch, int flags) {
+    const int want = gccnmf_tune_chain;
+    if (!want || want == 2 || want == 4 || !gccnmf_tune_fused_k12 || !gccnmf_tune_fused_k34 || gccnmf_tune_tile_policy != 0) return 0;
+    if (direct_path(g, batch) || (flags & 3) || batch < 8 || !g.tail || g.Fm < 64 || g.Fm > 512 || (g.Fm % 64) != 0 || g.K > 128) return 0;
+    if ((g.Fm / 64) * 16 < 32 * gccnmf_ceil_div(g.K, 32) || g.F > 64 * 9 || !gccnmf_tune_ring || (long)batch * (g.Kp / 64) >= 256) return 0;
+    if (want == 1 && !chain_rule(batch, flags)) return 0;
+    if (gccnmf_tune_ablate == 64) return 0;
+    return ((long)batch * (g.Kp / 32) >= 256 && gccnmf_tune_wide_update_w) ? 32 : 16;
+}
+
+static int launch_short_chain(const NmfGeom& g, const float* V, float* W, float* H, float* U, float* colsumW, float* rowsumH, float* hscale,
+                              float alpha, float eps, int batch, int group, unsigned* counters, int iterations, hipStream_t s) {
+    ShortChainArgs c = {};
+    c.a12.W = W; c.a12.sW = g.sW; c.a12.lda = g.Kp;
+    c.a12.H = H; c.a12.sH = g.sH; c.a12.ldb = g.ld;
+    c.a12.V = V; c.a12.sV = g.sV; c.a12.ldv = g.ld;
+    c.a12.scale = hscale; c.a12.colsum = colsumW; c.a12.sVec = g.Kp;
+    c.a12.M = g.Fm; c.a12.N = g.N; c.a12.Kd = g.K; c.a12.batch = batch;
+    c.a12.alpha = alpha; c.a12.eps = eps;
+    c.a34.W = W; c.a34.sW = g.sW; c.a34.lda = g.Kp;
+    c.a34.H = H; c.a34.sH = g.sH; c.a34.ldb = g.ld;
+    c.a34.V = V; c.a34.sV = g.sV; c.a34.ldv = g.ld;
+    c.a34.U = U; c.a34.sU = g.sU; c.a34.ldu = g.Kp;
+    c.a34.rowsumH = rowsumH; c.a34.sVec = g.Kp;
+    c.a34.M = g.Fm; c.a34.N = g.N; c.a34.Kd = g.K; c.a34.batch = batch;
+    c.aw.W = W; c.aw.U = U; c.aw.rowsumH = rowsumH; c.aw.colsumW = colsumW; c.aw.hscale = hscale;
+    c.aw.F = g.F; c.aw.K = g.K; c.aw.Kp = g.Kp; c.aw.sW = g.sW; c.aw.sU = g.sU; c.aw.sVec = g.Kp; c.aw.sRowsum = g.Kp;
+    c.it0 = 0; c.iterations = iterations; c.atoms_per_group = group; c.solo = gccnmf_tune_chain_solo;
+    c.counters = counters;
+    c.error = counters + chain_counter_floats(g, batch) - 32;
+    c.xcc_seen = c.error + 16;
+    return gccnmf_short_chain_launch(c, s);
+}
+
 // a consumer gave up waiting (GEMM_SYNC_TIMEOUT), or the workgroups of a list were NOT all on one XCD (the data hand-over through that XCD's
 // L2 is then not guaranteed): the factors cannot be trusted -- make them NaN so that nothing downstream looks plausible
 __global__ void nmf_chain_poison_kernel(const unsigned* __restrict__ err, float* __restrict__ W, float* __restrict__ H, long nW, long nH) {
@@ -1138,7 +1089,7 @@ int gccnmf_klnmf_plan(int F, int N, int K, int batch, int flags) {
     if (F < 2 || N < 1 || K < 1 || batch < 1) return -1;
     const NmfGeom g = make_geom(F, N, K);
     return (direct_path(g, batch) ? 1 : 0) | (fused_wh_updh(g, batch, flags) ? 2 : 0) | (fused_whdiv_rht_files(g, batch, flags) > 0 ? 4 : 0) |
-           (chain_stages(g, batch, flags) ? 8 : 0);
+           ((chain_stages(g, batch, flags) || short_chain_group(g, batch, flags)) ? 8 : 0);
 }
 
 int gccnmf_klnmf_stage(const float* V, float* W, float* H, float* workspace, int F, int N, int K, int batch,
@@ -1158,6 +1109,19 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     if ((rc = klnmf_stage(0, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s))) return rc;
     const int chained = chain_stages(g, batch, flags);          // 0 | 2: K1 | K2 in one launch | 4: the whole iteration | 8: the whole call
     unsigned* counters = (unsigned*)(workspace + klnmf_workspace_base_floats(g, batch));
+    const int short_group = chained ? 0 : short_chain_group(g, batch, flags);      // K <= 128: the three launches of every iteration as one chained launch
+    if (short_group && iterations > 0) {
+        if (hipMemsetAsync(counters, 0, sizeof(unsigned) * chain_counter_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+        float* R0 = workspace;
+        float* U0 = R0 + (long)batch * g.sV;
+        float* colsum0 = U0 + (long)batch * g.sU;
+        float* rowsum0 = colsum0 + (long)batch * g.Kp;
+        float* hscale0 = rowsum0 + (long)batch * g.Kp;
+        if ((rc = launch_short_chain(g, V, W, H, U0, colsum0, rowsum0, hscale0, sparsity_alpha, epsilon, batch, short_group, counters, iterations, s))) return rc;
+        hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
+        GCCNMF_CHECK_LAUNCH();
+        return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
+    }
     if (chained && iterations > 0 && hipMemsetAsync(counters, 0, sizeof(unsigned) * chain_counter_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     float* R = workspace;
     float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;

@@ -885,3 +885,68 @@ def test_wide_one_pass_w_update_at_batch_scale(hip):
         finally:
             lib.gccnmf_set_tuning(20, 1)
         assert rel(W.cpu().numpy(), W16.cpu().numpy()) < 1e-5 and rel(H.cpu().numpy(), H16.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('B,T,K,iters,alpha', [(64, 622, 128, 5, 0.0), (40, 311, 100, 6, 0.2), (24, 330, 64, 6, 0.0), (27, 100, 32, 4, 0.0)])
+def test_short_dictionary_chained_call(hip, B, T, K, iters, alpha):
+    """K <= 128 (the reference driver's K = 128: runGCCNMF.py:41): the three launches of an iteration -- K1 + K2 on column tiles, K3 + K4a on bin
+    slabs, the one-pass W update -- of EVERY iteration as ONE chained launch whose stages hand over per file (csrc/direct.hip:
+    gccnmf_short_chain_kernel; tuning key 21).  At 64 files the plain call runs the same three item programs: bit for bit the same factors.
+    At other batch sizes the plain call's launch forms follow the batch size: equal to summation order, and to the oracle."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    F, N = 513, 2 * T
+    rng = np.random.RandomState(B + K)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+
+    def run(chain):
+        from gcc_nmf_amd.engine import Geometry, padded
+        g = Geometry(F, T, K)
+        dV = padded(V, (B, g.Fp, g.Np), 'cuda')
+        dW = padded(np.repeat(W0[None], B, 0), (B, g.Fp, g.Kp), 'cuda')
+        dH = padded(np.repeat(H0[None], B, 0), (B, g.Kp, g.Np), 'cuda')
+        ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
+        assert lib.gccnmf_set_tuning(21, chain) == 0
+        assert bool(lib.gccnmf_klnmf_plan(F, N, K, B, 0) & 8) == bool(chain)
+        assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, iters, alpha, 1e-16, 0, stream()) == 0
+        torch.cuda.synchronize()
+        return dW, dH
+    try:
+        W, H = run(0)
+        Wc, Hc = run(8)
+        Wc2, Hc2 = run(8)
+    finally:
+        lib.gccnmf_set_tuning(21, 1)
+    assert torch.isfinite(Wc).all() and torch.isfinite(Hc).all()
+    assert torch.equal(Wc, Wc2) and torch.equal(Hc, Hc2)
+    assert not Wc[:, F:].any() and not Wc[:, :, K:].any() and not Hc[:, K:].any() and not Hc[:, :, N:].any()      # the padding stays exactly zero
+    if B == 64:
+        assert lib.gccnmf_klnmf_plan(F, N, K, B, 0) & 6 == 6
+        assert torch.equal(Wc, W) and torch.equal(Hc, H)
+    else:
+        assert rel(Wc.cpu().numpy(), W.cpu().numpy()) < 1e-5 and rel(Hc.cpu().numpy(), H.cpu().numpy()) < 1e-5
+    for b in (0, B - 1):
+        Wr, Hr = O.performKLNMF(V[b], K, iters, alpha)
+        assert rel(Wc[b, :F, :K].cpu().numpy(), Wr) < 1e-4 and rel(Hc[b, :K, :N].cpu().numpy(), Hr) < 1e-4
+
+
+def test_short_dictionary_chained_call_with_one_workgroup_per_cu(hip):
+    lib = hip.lib()
+    if lib.gccnmf_set_tuning(22, 1) != 0:
+        pytest.skip('key 22 (chained launches with one workgroup per CU) exists in experiment builds only: make EXPERIMENTS=1')
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    B, T, K, iters = 32, 311, 128, 4
+    F, N = 513, 2 * T
+    rng = np.random.RandomState(9)
+    V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+    W0, H0 = klnmf_initial_factors(F, N, K)
+    try:
+        assert lib.gccnmf_set_tuning(21, 8) == 0
+        Ws, Hs = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        assert lib.gccnmf_set_tuning(22, 0) == 0
+        Wc, Hc = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+    finally:
+        lib.gccnmf_set_tuning(22, 0)
+        lib.gccnmf_set_tuning(21, 1)
+    assert torch.isfinite(Ws).all() and torch.equal(Ws, Wc) and torch.equal(Hs, Hc)

@@ -204,7 +204,7 @@ def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
     # bit 3: the whole call as one chained launch -- K > 256, at least three files per XCD, the longest whole-file list at most 8 % above
     # the mean, no other file group beside it (round 6, profiles/r06h_files_sweep_*.txt)
     assert [plan(513, 1244, 1024, b, 0) for b in (16, 24, 25, 26, 32, 51, 52, 77, 104)] == [0, 8, 0, 0, 8, 0, 8, 8, 8]
-    assert plan(513, 1244, 1024, 32, 4 | (2 << 8)) == 0 and plan(513, 1244, 128, 64, 0) & 8 == 0 and plan(513, 1244, 256, 64, 0) == 8 and plan(513, 1244, 320, 64, 0) == 0 and plan(513, 1244, 384, 64, 0) == 8
+    assert plan(513, 1244, 1024, 32, 4 | (2 << 8)) == 0 and plan(513, 1244, 256, 64, 0) == 8 and plan(513, 1244, 320, 64, 0) == 0 and plan(513, 1244, 384, 64, 0) == 8
     assert plan(513, 1244, 1024, 64, 1) == 0 and plan(513, 1244, 1024, 64, 2) == 0              # no XCD-affine lists / unfused W update: plain launches
     try:
         assert lib.gccnmf_set_tuning(21, 0) == 0 and plan(513, 1244, 1024, 64, 0) == 0
@@ -212,11 +212,13 @@ def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
         assert lib.gccnmf_set_tuning(21, 3) == 1
     finally:
         lib.gccnmf_set_tuning(21, 1)
-    assert plan(513, 1244, 128, 64, 0) == 6 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
-    assert plan(513, 1244, 128, 96, 0) == 6 and plan(513, 1244, 128, 128, 0) == 6                # 96: a round of 64 files on the slabs, 32 behind it
+    # (bit 3 beside them: from 24 files in balanced whole-file lists the three launches of EVERY iteration run as one chained launch, round 6)
+    assert plan(513, 1244, 128, 64, 0) == 6 | 8 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
+    assert plan(513, 1244, 128, 96, 0) == 6 | 8 and plan(513, 1244, 128, 128, 0) == 6            # 96: a round of 64 files on the slabs, 32 behind it; 128 files: the two-pass W update
+    assert plan(513, 1244, 128, 40, 0) & 8 and plan(513, 1244, 64, 64, 0) & 8 and not plan(513, 1244, 128, 16, 0) & 8
     assert plan(513, 1244, 129, 64, 0) == 0 and plan(500, 1244, 128, 64, 0) == 0                # K > 128 / F not 64 n + 1: the batched tiles
     groups = lambda n: 4 | (n << 8)
-    assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2
+    assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2 | 8
     assert plan(513, 0, 128, 64, 0) == -1
     try:
         assert lib.gccnmf_set_tuning(16, 0) == 0 and lib.gccnmf_set_tuning(17, 2) == 0
