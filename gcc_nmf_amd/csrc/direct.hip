@@ -647,13 +647,14 @@ struct WhUpdhLds {
 };
 // One work item: column tile tn of file `file`.  trace: this item's 8-slot timeline row, or nullptr.
 template <int KB>
-__device__ __forceinline__ void gccnmf_wh_updh_item(const WhUpdhArgs& p, const int file, const int tn, float* const smem, long long* const trace) {
+__device__ __forceinline__ void gccnmf_wh_updh_item(const WhUpdhArgs& p, const int file, const int tn, float* const smem, long long* const trace,
+                                                    const int tid_in) {
     constexpr int PW = 129, NT = 16 * KB, NK = 32 * KB;          // LDS pitch | MFMA steps of the first product | padded atoms
     float (*Ws)[64][PW] = (float (*)[64][PW])smem;               // [2][64][PW]
     float* const s_wm = smem + 2 * 64 * PW;                      // [NK]
     float* const s_r = s_wm + NK;                                // [64]
     const int col0 = tn * 64;
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int tid = tid_in, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fg = wave & 1, nh = wave >> 1;
     const float* __restrict__ W = p.W + file * p.sW;            // [M + 1][lda]
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_wh_updh_kernel(const WhUpdhArgs
     }
     const int file = __builtin_amdgcn_readfirstlane(idx / tiles);
     const int tn = __builtin_amdgcn_readfirstlane(idx - file * tiles);
-    gccnmf_wh_updh_item<KB>(p, file, tn, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr);
+    gccnmf_wh_updh_item<KB>(p, file, tn, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr, (int)threadIdx.x);
 }
 
 
@@ -879,12 +880,13 @@ struct WhdivRhtLds {
 };
 // One work item: slab sl (64 bins) of file `file`.
 template <int KB>
-__device__ __forceinline__ void gccnmf_whdiv_rht_item(const WhdivRhtArgs& p, const int file, const int sl, float* const smem, long long* const trace) {
+__device__ __forceinline__ void gccnmf_whdiv_rht_item(const WhdivRhtArgs& p, const int file, const int sl, float* const smem, long long* const trace,
+                                                      const int tid_in) {
     constexpr int P = 68, NCH = 2 * KB, KR = 32 * KB;             // LDS pitch | chunks of 16 atoms | atom rows of the H tile
     float (*Hs)[KR][P] = (float (*)[KR][P])smem;                  // [2][KR][P] (16-byte aligned: smem is, P is a multiple of 4)
     float* const s_w = smem + 2 * KR * P;                         // [KR]
     float (*s_tail)[4][4][2] = (float (*)[4][4][2])(s_w + KR);    // [4][4][4][2]
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int tid = tid_in, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ W = p.W + file * p.sW;
     const float* __restrict__ H = p.H + file * p.sH;
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_whdiv_rht_kernel(const WhdivRht
     }
     const int file = __builtin_amdgcn_readfirstlane(idx / per_file);
     const int sl = __builtin_amdgcn_readfirstlane(idx - file * per_file);
-    gccnmf_whdiv_rht_item<KB>(p, file, sl, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr);
+    gccnmf_whdiv_rht_item<KB>(p, file, sl, smem, p.trace ? p.trace + 8 * (long)blockIdx.x : nullptr, (int)threadIdx.x);
 }
 
 
@@ -1175,13 +1177,13 @@ __global__ __launch_bounds__(256, 2) void gccnmf_short_chain_kernel(const ShortC
     if (tr && tid == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
     gemm_sync_wait(y, file, 0, tid, it, list, 0);
     if (stage == 0) {
-        gccnmf_wh_updh_item<KB>(c.a12, file, sub, smem, tr);
+        gccnmf_wh_updh_item<KB>(c.a12, file, sub, smem, tr, tid);
     } else if (stage == 1) {
-        gccnmf_whdiv_rht_item<KB>(c.a34, file, sub, smem, tr);
+        gccnmf_whdiv_rht_item<KB>(c.a34, file, sub, smem, tr, tid);
     } else {
         if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
         nmf_update_w_onepass_item<AT, 1>(c.aw.W, c.aw.U, c.aw.rowsumH, c.aw.colsumW, c.aw.hscale, c.aw.F, c.aw.K, c.aw.Kp, c.aw.sW, c.aw.sU, c.aw.sVec,
-                                         c.aw.sRowsum, 0, 0, nullptr, 0, 0, file, sub, smem);
+                                         c.aw.sRowsum, 0, 0, nullptr, 0, 0, file, sub, smem, tid);
         if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
     }
     gemm_sync_signal(y, file, 0, 1, tid);

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void nmf_update_w_onepass_kernel(float* __rest
     __shared__ __attribute__((aligned(16))) float smem[5 * AT];
     const int chunks = Kp / AT;
     const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
-    nmf_update_w_onepass_item<AT, NSPLIT>(W, U, rowsumH, colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR, Wt, sWt, ldwt, b, ch, smem);
+    nmf_update_w_onepass_item<AT, NSPLIT>(W, U, rowsumH, colsumW, hscale, F, K, Kp, sW, sU, sVec, sRowsum, sSplitU, sSplitR, Wt, sWt, ldwt, b, ch, smem, (int)threadIdx.x);
 }
 
 static int launch_update_w(float* W, const float* U, const float* rowsumH, float* colsumW, float* hscale, int F, int Fp, int K,

@@ -1,6 +1,7 @@
 // The W update + normalisation of one group of AT atoms of one file in ONE pass (gccNMFFunctions.py:77, :79-80): the device function behind
 // nmf_update_w_onepass_kernel (nmf.hip) and the W-update stage of the short-dictionary chained launch (direct.hip).
-//   smem: 5 * AT floats of LDS.  b: file, ch: atom group.
+//   smem: 5 * AT floats of LDS.  b: file, ch: atom group.  tid: the thread index (a caller that loops over items passes an opaque copy, so that
+//   nothing derived from it becomes an invariant of that loop).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,14 +9,14 @@ template <int AT, int NSPLIT>
 __device__ __forceinline__ void nmf_update_w_onepass_item(float* __restrict__ W, const float* __restrict__ U, const float* __restrict__ rowsumH,
                                                           float* __restrict__ colsumW, float* __restrict__ hscale, int F, int K, int Kp, long sW,
                                                           long sU, long sVec, long sRowsum, long sSplitU, long sSplitR, float* __restrict__ Wt,
-                                                          long sWt, int ldwt, const int b, const int ch, float* const smem) {
+                                                          long sWt, int ldwt, const int b, const int ch, float* const smem, const int tid) {
     constexpr int nsplit = NSPLIT;
     constexpr int L4 = AT / 4;                 // float4 lanes per row segment
     constexpr int PH = 256 / L4;               // row phases per workgroup (PH / 4 per wave)
     constexpr int R = (64 * 9 + PH - 1) / PH;  // rows per thread for F <= 576
     float (*red)[AT] = (float (*)[AT])smem;          // [4][AT]
     float* s_norm = smem + 4 * AT;                    // [AT]
-    const int c4 = threadIdx.x % L4, q = threadIdx.x / L4, wave = threadIdx.x >> 6;
+    const int c4 = tid % L4, q = tid / L4, wave = tid >> 6;
     const int k0 = ch * AT + 4 * c4;
     const bool v0 = k0 < K, v1 = k0 + 1 < K, v2 = k0 + 2 < K, v3 = k0 + 3 < K;      // padded atoms stay exactly zero
     float* Wb = W + b * sW;
@@ -69,9 +70,9 @@ __device__ __forceinline__ void nmf_update_w_onepass_item(float* __restrict__ W,
         return v;
     };
     ss = reduce_wave(ss);
-    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = ss;
+    if ((tid & 63) < L4) *(float4*)&red[wave][4 * c4] = ss;
     __syncthreads();
-    if (threadIdx.x < AT) s_norm[threadIdx.x] = sqrtf((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (tid < AT) s_norm[tid] = sqrtf((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
     __syncthreads();
     const float4 nm = *(const float4*)&s_norm[4 * c4];
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -91,11 +92,11 @@ __device__ __forceinline__ void nmf_update_w_onepass_item(float* __restrict__ W,
     }
     cs = reduce_wave(cs);
     __syncthreads();
-    if ((threadIdx.x & 63) < L4) *(float4*)&red[wave][4 * c4] = cs;
+    if ((tid & 63) < L4) *(float4*)&red[wave][4 * c4] = cs;
     __syncthreads();
-    if (threadIdx.x < AT && ch * AT + (int)threadIdx.x < K) {
-        const int k = ch * AT + threadIdx.x;
-        colsumW[b * sVec + k] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        hscale[b * sVec + k] = s_norm[threadIdx.x];
+    if (tid < AT && ch * AT + tid < K) {
+        const int k = ch * AT + tid;
+        colsumW[b * sVec + k] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        hscale[b * sVec + k] = s_norm[tid];
     }
 }
