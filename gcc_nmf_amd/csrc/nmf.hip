@@ -931,7 +931,9 @@ static int short_chain_group(const NmfGeom& g, int batch, int flags) {
     if (!want || want == 2 || want == 4 || !gccnmf_tune_fused_k12 || !gccnmf_tune_fused_k34 || gccnmf_tune_tile_policy != 0) return 0;
     if (direct_path(g, batch) || (flags & 3) || batch < 8 || !g.tail || g.Fm < 64 || g.Fm > 512 || (g.Fm % 64) != 0 || g.K > 128) return 0;
     if ((g.Fm / 64) * 16 < 32 * gccnmf_ceil_div(g.K, 32) || g.F > 64 * 9 || !gccnmf_tune_ring || (long)batch * (g.Kp / 64) >= 256) return 0;
-    if (want == 1 && !chain_rule(batch, flags)) return 0;
+    // by rule: only where the plain call runs the SAME three item programs for every file (both fused launches, no files left to the two-launch
+    // form) -- the chained call is then bit for bit the plain one, and a file's bits keep following the batch size exactly as before
+    if (want == 1 && !(chain_rule(batch, flags) && fused_wh_updh(g, batch, flags) && fused_whdiv_rht_files(g, batch, flags) == batch)) return 0;
     if (gccnmf_tune_ablate == 64) return 0;
     return ((long)batch * (g.Kp / 32) >= 256 && gccnmf_tune_wide_update_w) ? 32 : 16;
 }

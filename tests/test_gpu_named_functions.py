@@ -135,3 +135,79 @@ def test_benchmark_batch_at_200_iterations():
         assert rms < 1e-5, (b, rms)
         print('bench file %d at 200 iterations: W rel %.2e H rel %.2e mask flips %d (largest oracle gap %.1e) waveform rms %.2e'
               % (b, rw, rh, int(flipped.sum()), gaps.max() if len(gaps) else 0, rms))
+
+
+def test_returned_arrays_own_their_page_locked_blocks(dropin_mode):
+    """The named functions return arrays BASED on pooled page-locked blocks (gcc_nmf_amd/_staging.py): a block goes back to the pool only when
+    the last array (or view) over it is gone -- so an earlier result must stay intact through any number of later calls, in both modes, and
+    a view keeps its block alive after the array it was taken from is dropped."""
+    import gc
+    from gcc_nmf_amd import gccNMFFunctions as G
+    from gcc_nmf_amd.synthetic import synthetic_mixture
+    x1, x2 = synthetic_mixture(31, numSamples=30000), synthetic_mixture(32, numSamples=30000)
+    X1 = G.computeComplexMixtureSpectrogram(x1, 1024, 256, np.hanning)
+    keep = X1.copy()
+    row = X1[1, 100]                                   # a view: the only reference to the block once X1 is dropped
+    row_keep = row.copy()
+    assert X1.flags.writeable == (dropin_mode == 'copying')
+    for _ in range(4):
+        X2 = G.computeComplexMixtureSpectrogram(x2, 1024, 256, np.hanning)
+        assert np.array_equal(X1, keep) and not np.array_equal(X2, keep)
+    del X1
+    gc.collect()
+    for _ in range(4):
+        X2 = G.computeComplexMixtureSpectrogram(x2, 1024, 256, np.hanning)
+    assert np.array_equal(row, row_keep)
+    # the same spectrogram again: same bits whether the block is fresh or recycled
+    assert np.array_equal(G.computeComplexMixtureSpectrogram(x1, 1024, 256, np.hanning), keep)
+
+
+def test_resident_mode_recognises_only_untouched_objects():
+    """dropin.install(resident=True): the device image behind a returned array is reused only for THAT object while it is read-only; a copy,
+    a view or an array made writable again is uploaded like any other argument -- same results on every route."""
+    from gcc_nmf_amd import gccNMFFunctions as G, _staging
+    from gcc_nmf_amd.synthetic import synthetic_mixture
+    x = synthetic_mixture(33, numSamples=40000)
+    try:
+        G.set_resident(True)
+        X = G.computeComplexMixtureSpectrogram(x, 1024, 256, np.hanning)
+        V = np.concatenate(abs(X), axis=-1)
+        W, H = G.performKLNMF(V, 48, 8, 0)
+        stereoH = np.array(np.hsplit(H, 2))
+        assert not X.flags.writeable and not W.flags.writeable
+        dev = G._device()
+        assert _staging.lookup(X, 'X', dev) is not None and _staging.lookup(W, 'W', dev) is not None
+        assert _staging.lookup(X.copy(), 'X', dev) is None and _staging.lookup(X[:], 'X', dev) is None and _staging.lookup(W, 'X', dev) is None
+        M = (np.random.RandomState(0).rand(3, 48, X.shape[2]) > 0.5).astype(np.float32)
+        S_res = G.getTargetSpectrogramEstimates(M, X, W, stereoH)                       # X and W from their device images
+        S_up = G.getTargetSpectrogramEstimates(M, X.copy(), W.copy(), stereoH)          # everything uploaded
+        # (the resident route takes |X| from the STFT epilogue, the uploaded one from gccnmf_magnitude: the same hypotf)
+        assert np.array_equal(S_res, S_up)
+        Wc = W.copy()
+        Wc[:, 0] = 0                                                                      # a modified copy is just another array
+        S_mod = G.getTargetSpectrogramEstimates(M, X, Wc, stereoH)
+        assert not np.array_equal(S_mod, S_res)
+        y_res = G.getTargetSignalEstimates(S_res, 1024, 256, np.hanning)
+        y_up = G.getTargetSignalEstimates(S_res.copy(), 1024, 256, np.hanning)
+        assert np.array_equal(y_res, y_up)
+        G.set_resident(False)
+        assert _staging.lookup(X, 'X', dev) is None and not _staging._RESIDENT
+        assert G.computeComplexMixtureSpectrogram(x, 1024, 256, np.hanning).flags.writeable
+    finally:
+        G.set_resident(False)
+
+
+def test_magnitude_entry_point():
+    """gccnmf_magnitude: V = concatenate(abs(X), axis=-1) (runGCCNMF.py:40) from a spectrogram already on the device, the same hypotf as the STFT epilogue."""
+    from gcc_nmf_amd import _hip
+    from gcc_nmf_amd.engine import GCCNMFEngine
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    e = GCCNMFEngine(30000, dictionarySize=16, numIterations=1, batch=3)
+    e.upload(synthetic_batch(50, 3, numSamples=30000))
+    e.stft()
+    V = torch.zeros_like(e.V)
+    assert _hip.lib().gccnmf_magnitude(e.X.data_ptr(), e.g.F, e.g.T, 3, V.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(V, e.V)
+    X = e.get_X()
+    assert np.abs(V[:, :e.g.F, :e.g.N].cpu().numpy() - np.concatenate([np.abs(X[:, 0]), np.abs(X[:, 1])], axis=-1)).max() < 1e-6 * np.abs(X).max()

@@ -212,13 +212,14 @@ def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
         assert lib.gccnmf_set_tuning(21, 3) == 1
     finally:
         lib.gccnmf_set_tuning(21, 1)
-    # (bit 3 beside them: from 24 files in balanced whole-file lists the three launches of EVERY iteration run as one chained launch, round 6)
+    # (bit 3 beside them, round 6: where the plain call runs both fused launches for EVERY file -- and the batch gives every XCD three whole files
+    # in balanced lists -- the three launches of every iteration run as ONE chained launch, bit for bit the plain call)
     assert plan(513, 1244, 128, 64, 0) == 6 | 8 and plan(513, 1244, 128, 25, 0) == 2 and plan(513, 1244, 128, 26, 0) == 0
-    assert plan(513, 1244, 128, 96, 0) == 6 | 8 and plan(513, 1244, 128, 128, 0) == 6            # 96: a round of 64 files on the slabs, 32 behind it; 128 files: the two-pass W update
-    assert plan(513, 1244, 128, 40, 0) & 8 and plan(513, 1244, 64, 64, 0) & 8 and not plan(513, 1244, 128, 16, 0) & 8
+    assert plan(513, 1244, 128, 96, 0) == 6 and plan(513, 1244, 128, 128, 0) == 6                # 96: a round of 64 files on the slabs, 32 behind it: no chain
+    assert plan(513, 1244, 128, 56, 0) == 14 and plan(513, 1244, 128, 40, 0) == 2 and plan(513, 1244, 64, 64, 0) == 14 and plan(513, 2486, 128, 64, 0) == 14
     assert plan(513, 1244, 129, 64, 0) == 0 and plan(500, 1244, 128, 64, 0) == 0                # K > 128 / F not 64 n + 1: the batched tiles
     groups = lambda n: 4 | (n << 8)
-    assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2 | 8
+    assert plan(513, 1244, 128, 32, groups(2)) == 6 and plan(513, 1244, 128, 16, groups(4)) == 6 and plan(513, 1244, 128, 32, 0) == 2
     assert plan(513, 0, 128, 64, 0) == -1
     try:
         assert lib.gccnmf_set_tuning(16, 0) == 0 and lib.gccnmf_set_tuning(17, 2) == 0
