@@ -31,6 +31,8 @@ _PINNED_FREE = {}                        # rounded bytes -> [uint8 pinned tensor
 _PINNED_FREE_BYTES = [0]
 PINNED_POOL_LIMIT = 1 << 30              # free page-locked bytes kept for re-use; beyond it blocks are simply freed
 _DEVICE_FREE = {}                        # (tag, shape, corner, dtype, device index) -> [tensors]
+_DEVICE_FREE_BYTES = [0]
+DEVICE_POOL_LIMIT = 8 << 30              # free device bytes kept for re-use (a process that walks through many shapes does not keep them all)
 _RESIDENT = {}                           # id(ndarray) -> _Resident
 _resident_mode = [False]
 
@@ -91,6 +93,22 @@ def host_array(shape, dtype):
     return arr, t
 
 
+def _give_device(key, t):
+    nbytes = t.numel() * t.element_size()
+    if _DEVICE_FREE_BYTES[0] + nbytes <= DEVICE_POOL_LIMIT:
+        _DEVICE_FREE.setdefault(key, []).append(t)
+        _DEVICE_FREE_BYTES[0] += nbytes
+
+
+def _take_device(key):
+    free = _DEVICE_FREE.get(key)
+    if not free:
+        return None
+    t = free.pop()
+    _DEVICE_FREE_BYTES[0] -= t.numel() * t.element_size()
+    return t
+
+
 class _Resident(object):
     """The device image(s) behind one returned ndarray."""
 
@@ -106,7 +124,7 @@ class _Resident(object):
         if _RESIDENT.get(self.key) is self:
             del _RESIDENT[self.key]
         for key, t in self.leases:
-            _DEVICE_FREE.setdefault(key, []).append(t)
+            _give_device(key, t)
         self.leases = []
 
 
@@ -135,8 +153,9 @@ class Scope(object):
         re-used for a different corner, so stale data can never sit in what another call treats as zero padding)."""
         shape = tuple(int(s) for s in shape)
         key = (tag, shape, None if corner is None else tuple(int(c) for c in corner), dtype, self.device.index)
-        free = _DEVICE_FREE.get(key)
-        t = free.pop() if free else torch.zeros(shape, dtype=dtype, device=self.device)
+        t = _take_device(key)
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
         self._dev.append((key, t))
         return t
 
@@ -185,7 +204,7 @@ class Scope(object):
         self.stream.synchronize()
         for key, t in self._dev:
             if id(t) not in self._kept:
-                _DEVICE_FREE.setdefault(key, []).append(t)
+                _give_device(key, t)
         for pin in self._pinned:
             _give_pinned(pin)
         self._dev, self._pinned = [], []
@@ -217,6 +236,7 @@ def clear():
     for rec in list(_RESIDENT.values()):
         rec.drop()
     _DEVICE_FREE.clear()
+    _DEVICE_FREE_BYTES[0] = 0
     _PINNED_FREE.clear()
     _PINNED_FREE_BYTES[0] = 0
     _CONSTANTS.clear()

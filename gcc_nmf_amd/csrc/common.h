@@ -56,6 +56,7 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //                                        an iteration, 8 = every iteration of the call
 //   23   chain_rag         1     0..1    chained launches on whole-file lists: list x = files x, x + 8, ..., a file's ragged tiles behind its wide ones; any batch >= 13
 //                                        (0: the plain launch's lists -- equal eighths, short items last -- batch a multiple of 8 only)
+//   24   chain_chunk     2048   1..65536 iterations per chained launch: a call of more iterations runs as several chained launches (the counters keep counting)
 //    1 X ablate            0             timing ablations of the register-staged kernel (results invalid)
 //    4 X ring              1     0..1    0 = small-batch tiles on the register-staged kernel instead of the LDS-DMA ring kernel
 //    5 X wh_splits         3     1..4    parts of the single-file split-K W.H (the round-3 latency path, superseded by direct.hip)
@@ -68,7 +69,7 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //   19 X prefetch          1     0..1    1 = a resident workgroup requests its next tile's first k-tile before the current epilogue
 //   20 X wide_update_w     1     0..1    0 = the one-pass W update of short dictionaries at batch scale on 16 atoms per workgroup (round 4)
 //   22 X chain_solo        0     0..1    1 = chained launches reserve enough LDS that only ONE workgroup fits a CU (in-order dispatch => no deadlock: tested)
-#define GCCNMF_TUNE_KEYS 24
+#define GCCNMF_TUNE_KEYS 25
 struct GccNmfTune {
     int v[GCCNMF_TUNE_KEYS];
 };
@@ -101,3 +102,4 @@ struct GccNmfCall {
 #define gccnmf_tune_chain (gccnmf_tune.v[21])
 #define gccnmf_tune_chain_solo (gccnmf_tune.v[22])
 #define gccnmf_tune_chain_rag (gccnmf_tune.v[23])
+#define gccnmf_tune_chain_chunk (gccnmf_tune.v[24])

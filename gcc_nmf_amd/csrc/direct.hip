@@ -1204,7 +1204,7 @@ int gccnmf_short_chain_launch(ShortChainArgs a, hipStream_t stream) {
     const int longest = (a.a12.batch + 7) / 8;
     a.first[0] = 0;
     for (int i = 0; i < 3; ++i) a.first[i + 1] = a.first[i] + longest * a.per_file[i];
-    if ((long)8 * a.first[3] * a.iterations > (1L << 30) || a.it0 != 0) return GCCNMF_ERR_ARG;
+    if ((long)8 * a.first[3] * a.iterations > (1L << 30)) return GCCNMF_ERR_ARG;
     a.trace = gccnmf_trace_buf;
     a.trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks : 0;
     a.trace_it = a.it0 + a.iterations - 1;

@@ -23,6 +23,7 @@ int gccnmf_launch_gemm_stream(GemmArgs a, hipStream_t stream);       // the LDS-
 #include <algorithm>
 #include <vector>
 #define GCCNMF_SHARED_STREAMS 4
+#define GCCNMF_CHAIN_MAX_ITERATIONS gccnmf_tune_chain_chunk   // iterations per chained launch (tuning key 24, default 2048: the grid stays far below 2^30 workgroups)
 #define GCCNMF_RAGGED_MAX_BATCH 248   // files of a ragged batch: 8 lists of at most GEMM_RAGGED_LMAX
 #define GCCNMF_SPLITS 4           // parts of the round-3 single-file split-K (experiment builds); the workspace layout keeps room for them
 #define GCCNMF_DIRECT_MAX_BATCH 8    // workspaces of at most this many files carry the transposed copies of the direct path (key 12 selects up to here; from 8 files on
@@ -57,6 +58,7 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
                                         //    2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call
     {0, 0, 1, 1},                       // 22 chain_solo: chained launches with one workgroup per CU (the freedom-from-deadlock test)
     {1, 0, 1, 0},                       // 23 chain_rag: chained launches on whole-file lists (0: the plain launch's lists, batch a multiple of 8 only)
+    {2048, 1, 65536, 0},                // 24 chain_chunk: iterations per chained launch (a call of more iterations is several launches; tests use small values)
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
 static std::atomic<int> gccnmf_knobs_ready{0};
@@ -896,14 +898,16 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
         ch.sync[3].wait_cnt = c34; ch.sync[3].wait_stride = 1; ch.sync[3].wait_per_tile = 0;
         ch.sync[3].wait_need = (unsigned)(a[2].tiles_m * (rg ? 1 : a[2].tiles_n));
         ch.sync[3].wait_scale_tiles = rg ? 1 : 0;
-        if (iterations > 1) {
-            // K4 -> the next iteration's K1: every atom tile of the file (W, its column sums and the pending row scale are complete; R is free)
+        {
+            // K4 -> the next iteration's K1 (also across launches: a call of very many iterations is a few chained launches, and forced per-iteration
+            // launches keep counting -- the kernel boundary makes the wait trivially true there): every atom tile of the file (W, its column sums and the pending row scale are complete; R is free)
             ch.sync[3].sig_cnt = c41; ch.sync[3].sig_stride = 1; ch.sync[3].sig_per_tile = 0;
             ch.sync[0].wait_cnt = c41; ch.sync[0].wait_stride = 1; ch.sync[0].wait_per_tile = 0; ch.sync[0].wait_lag = 1;
             ch.sync[0].wait_need = (unsigned)(a[3].tiles_m * a[3].tiles_n);
         }
     }
     if (iterations > 1 && stages != 4) return GCCNMF_ERR_ARG;
+    if (it0 == 0 && iterations == 1) ch.sync[0].wait_cnt = nullptr;      // (nothing to wait for: the counters were just zeroed)
     ch.it0 = it0; ch.iterations = iterations;
     ch.trace_it = it0 + iterations - 1;
     if ((long)8 * ch.first[4] * iterations > (1L << 30)) return GCCNMF_ERR_ARG;
@@ -939,7 +943,7 @@ static int short_chain_group(const NmfGeom& g, int batch, int flags) {
 }
 
 static int launch_short_chain(const NmfGeom& g, const float* V, float* W, float* H, float* U, float* colsumW, float* rowsumH, float* hscale,
-                              float alpha, float eps, int batch, int group, unsigned* counters, int iterations, hipStream_t s) {
+                              float alpha, float eps, int batch, int group, unsigned* counters, int it0, int iterations, hipStream_t s) {
     ShortChainArgs c = {};
     c.a12.W = W; c.a12.sW = g.sW; c.a12.lda = g.Kp;
     c.a12.H = H; c.a12.sH = g.sH; c.a12.ldb = g.ld;
@@ -955,7 +959,7 @@ static int launch_short_chain(const NmfGeom& g, const float* V, float* W, float*
     c.a34.M = g.Fm; c.a34.N = g.N; c.a34.Kd = g.K; c.a34.batch = batch;
     c.aw.W = W; c.aw.U = U; c.aw.rowsumH = rowsumH; c.aw.colsumW = colsumW; c.aw.hscale = hscale;
     c.aw.F = g.F; c.aw.K = g.K; c.aw.Kp = g.Kp; c.aw.sW = g.sW; c.aw.sU = g.sU; c.aw.sVec = g.Kp; c.aw.sRowsum = g.Kp;
-    c.it0 = 0; c.iterations = iterations; c.atoms_per_group = group; c.solo = gccnmf_tune_chain_solo;
+    c.it0 = it0; c.iterations = iterations; c.atoms_per_group = group; c.solo = gccnmf_tune_chain_solo;
     c.counters = counters;
     c.error = counters + chain_counter_floats(g, batch) - 32;
     c.xcc_seen = c.error + 16;
@@ -1119,7 +1123,10 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
         float* colsum0 = U0 + (long)batch * g.sU;
         float* rowsum0 = colsum0 + (long)batch * g.Kp;
         float* hscale0 = rowsum0 + (long)batch * g.Kp;
-        if ((rc = launch_short_chain(g, V, W, H, U0, colsum0, rowsum0, hscale0, sparsity_alpha, epsilon, batch, short_group, counters, iterations, s))) return rc;
+        for (int it0 = 0; it0 < iterations; it0 += GCCNMF_CHAIN_MAX_ITERATIONS)
+            if ((rc = launch_short_chain(g, V, W, H, U0, colsum0, rowsum0, hscale0, sparsity_alpha, epsilon, batch, short_group, counters, it0,
+                                         std::min(GCCNMF_CHAIN_MAX_ITERATIONS, iterations - it0), s)))
+                return rc;
         hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
         GCCNMF_CHECK_LAUNCH();
         return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
@@ -1129,7 +1136,10 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;
     float* hscale = colsumW + 2L * batch * g.Kp;
     if (chained == 8 && iterations > 0) {
-        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, 0, iterations, s))) return rc;
+        for (int it0 = 0; it0 < iterations; it0 += GCCNMF_CHAIN_MAX_ITERATIONS)      // (one launch; a call of thousands of iterations: a few, the grid stays below 2^30 workgroups)
+            if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, it0,
+                                         std::min(GCCNMF_CHAIN_MAX_ITERATIONS, iterations - it0), s)))
+                return rc;
     } else {
         for (int it = 0; it < iterations; ++it) {
             if (chained && (rc = launch_klnmf_chain(chained, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags, counters, it, 1, s))) return rc;
@@ -1209,7 +1219,10 @@ int gccnmf_klnmf_ragged(const float* V, float* W, float* H, float* workspace, in
         float* R = workspace;
         float* colsumW = R + (long)batch * g.sV + (long)batch * g.sU;
         float* hscale = colsumW + 2L * batch * g.Kp;
-        if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags & ~4, counters, 0, iterations, s, &rg))) return rc;
+        for (int it0 = 0; it0 < iterations; it0 += GCCNMF_CHAIN_MAX_ITERATIONS)
+            if ((rc = launch_klnmf_chain(4, g, V, W, H, R, colsumW, hscale, sparsity_alpha, epsilon, batch, flags & ~4, counters, it0,
+                                         std::min(GCCNMF_CHAIN_MAX_ITERATIONS, iterations - it0), s, &rg)))
+                return rc;
         hipLaunchKernelGGL(nmf_chain_poison_kernel, dim3(64), dim3(256), 0, s, counters + chain_counter_floats(g, batch) - 32, W, H, (long)batch * g.sW, (long)batch * g.sH);
         GCCNMF_CHECK_LAUNCH();
     }

@@ -950,3 +950,28 @@ def test_short_dictionary_chained_call_with_one_workgroup_per_cu(hip):
         lib.gccnmf_set_tuning(22, 0)
         lib.gccnmf_set_tuning(21, 1)
     assert torch.isfinite(Ws).all() and torch.equal(Ws, Wc) and torch.equal(Hs, Hc)
+
+
+def test_a_long_call_is_several_chained_launches(hip):
+    """A call of more iterations than one chained launch takes (tuning key 24, default 2048) continues in further launches on the same counters:
+    with 3 iterations per launch an 8-iteration call is 3 + 3 + 2 -- bit for bit the one-launch call and the plain one, K > 128 and K <= 128."""
+    lib = hip.lib()
+    from gcc_nmf_amd.engine import klnmf_initial_factors
+    for B, T, K in [(16, 622, 1024), (24, 100, 64)]:
+        F, N, iters = 513, 2 * T, 8
+        rng = np.random.RandomState(K)
+        V = (np.abs(rng.standard_normal((B, F, N))) + 0.01).astype(np.float32)
+        W0, H0 = klnmf_initial_factors(F, N, K)
+        try:
+            assert lib.gccnmf_set_tuning(21, 8) == 0
+            assert lib.gccnmf_klnmf_plan(F, N, K, B, 0) & 8
+            W1, H1 = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+            assert lib.gccnmf_set_tuning(24, 3) == 0
+            W3, H3 = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+            assert lib.gccnmf_set_tuning(24, 1) == 0
+            Wq, Hq = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        finally:
+            lib.gccnmf_set_tuning(21, 1)
+            lib.gccnmf_set_tuning(24, 2048)
+        assert torch.isfinite(W1).all()
+        assert torch.equal(W3, W1) and torch.equal(H3, H1) and torch.equal(Wq, W1) and torch.equal(Hq, H1)
