@@ -57,6 +57,7 @@ SIGNATURES = {
     'gccnmf_klnmf_ragged_workspace_floats': (c_long, [c_int, c_int, c_int, c_int]),
     'gccnmf_klnmf_ragged': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, P_INT, c_int, c_int, c_int, c_int, c_float,
                                     c_float, c_int, c_void_p]),
+    'gccnmf_klnmf_chain_status': (c_int, [c_void_p, c_int, c_int, c_int, c_int, P_INT]),
     'gccnmf_klnmf_plan': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'gccnmf_klnmf_stage': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                    c_int, c_int, c_void_p]),

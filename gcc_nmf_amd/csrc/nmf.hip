@@ -1154,6 +1154,24 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     return klnmf_stage(6, V, W, H, workspace, g, batch, sparsity_alpha, epsilon, flags, s);
 }
 
+// Did the chained launches of the LAST gccnmf_klnmf / gccnmf_klnmf_ragged call on this workspace hand over cleanly?  (The call itself is
+// asynchronous and poisons W, H with NaN if they did not; this is the explicit check: a blocking 4-byte read.)  status: 0 = clean (or the call
+// did not chain), bit 0 = a consumer gave up waiting for its producer (GEMM_SYNC_TIMEOUT), bit 1 = the workgroups of some list ran on more
+// than one XCC (the hand-over through one XCD's L2 is then not guaranteed).  N: the column count the workspace was sized with (Nmax for a ragged batch).
+int gccnmf_klnmf_chain_status(const float* workspace, int F, int N, int K, int batch, int* status) {
+    GCCNMF_ENTER();
+    if (!workspace || !status || F < 2 || N < 1 || K < 1 || batch < 1) return GCCNMF_ERR_ARG;
+    NmfGeom g = make_geom(F, N, K);
+    const unsigned* words = (const unsigned*)(workspace + klnmf_workspace_base_floats(g, batch)) + chain_counter_floats(g, batch) - 32;
+    unsigned host[32];
+    if (hipMemcpy(host, words, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return GCCNMF_ERR_LAUNCH;
+    int st = host[0] ? 1 : 0;
+    for (int l = 0; l < 8; ++l)
+        if (__builtin_popcount(host[16 + l]) > 1) st |= 2;
+    *status = st;
+    return GCCNMF_OK;
+}
+
 // ---- ragged batches: mixtures of different lengths in one call (gccNMF/runGCCNMF.py:30-36 separates a file of ANY length) -------------
 struct RaggedTables {
     int v[GCCNMF_RAGGED_MAX_BATCH + 8 * (GEMM_RAGGED_LMAX + 1)];

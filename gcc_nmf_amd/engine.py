@@ -437,9 +437,25 @@ class GCCNMFEngine(object):
 
     @_on_device
     def check_status(self):
+        self.check_chain_status()
         st = self.status.cpu().numpy()
         if st.any():
             raise ValueError('fewer than %d angular-spectrum peaks in file(s) %s' % (self.g.S, np.nonzero(st)[0].tolist()))
+
+    @_on_device
+    def check_chain_status(self):
+        """A chained KL-NMF launch whose hand-over failed has turned W and H into NaN; say so instead of letting NaN travel on."""
+        import ctypes
+        g, st = self.g, ctypes.c_int(0)
+        per = self.batch // self.nmf_groups
+        ws_per = self.ws_nmf.numel() // self.nmf_groups
+        torch.cuda.current_stream(self.device).synchronize()
+        for i in range(self.nmf_groups):
+            _hip.check(self.lib.gccnmf_klnmf_chain_status(_ptr(self.ws_nmf[i * ws_per:]), g.F, g.N, g.K, per, ctypes.byref(st)), 'gccnmf_klnmf_chain_status')
+            if st.value:
+                raise _hip.HipLibraryError('the chained KL-NMF launch did not hand over cleanly (status %d: %s): W and H of this batch are NaN.  '
+                                           'GCCNMF_TUNE="21=0" runs the plain launches.'
+                                           % (st.value, 'a consumer timed out' if st.value & 1 else 'a work list ran on more than one XCC'))
 
     # ---- views of device results in the reference's shapes ------------------------------------------
     def get_X(self):
@@ -542,6 +558,7 @@ class RaggedGCCNMFEngine(object):
                 rc = self.lib.gccnmf_klnmf_ragged(_ptr(r['V']), _ptr(r['W']), _ptr(r['H']), _ptr(r['ws']), g.F, r['N'], g.N, g.K, self.batch,
                                                   self.iters, self.alpha, self.eps, self.klnmf_flags, _stream())
                 if rc == 0:
+                    self._ragged_ran = True
                     for n, e in self.sub.items():
                         idx = torch.as_tensor(self.files_of[n], device=self.device)
                         e.W.copy_(r['W'][idx])
@@ -577,6 +594,14 @@ class RaggedGCCNMFEngine(object):
         self.upload(mixtures)
         self.run()
         out = [None] * self.batch
+        if self.ragged_klnmf_used:
+            import ctypes
+            st = ctypes.c_int(0)
+            torch.cuda.current_stream(self.device).synchronize()
+            _hip.check(self.lib.gccnmf_klnmf_chain_status(_ptr(self.ragged['ws']), self.g.F, self.g.N, self.g.K, self.batch, ctypes.byref(st)),
+                       'gccnmf_klnmf_chain_status')
+            if st.value:
+                raise _hip.HipLibraryError('the ragged chained KL-NMF launch did not hand over cleanly (status %d): W and H are NaN' % st.value)
         for n, e in self.sub.items():
             y = e.y.cpu().numpy()
             e.check_status()

@@ -143,6 +143,12 @@ long gccnmf_klnmf_ragged_workspace_floats(int F, int Nmax, int K, int batch);
 int gccnmf_klnmf_ragged(const float* V, float* W, float* H, float* workspace, int F, const int* N, int Nmax, int K, int batch,
                         int iterations, float sparsity_alpha, float epsilon, int flags, void* stream);
 
+/* After a synchronisation: did the chained launches of the last gccnmf_klnmf / gccnmf_klnmf_ragged call on `workspace` hand over cleanly?
+ * *status = 0: yes (or the call did not chain); bit 0: a consumer gave up waiting for its producer; bit 1: the workgroups of a work list ran
+ * on more than one XCC.  In both cases the call has already turned W and H into NaN (never plausible-looking garbage); this is the explicit
+ * check (a blocking 128-byte read).  F, N, K, batch as for the workspace size (N = Nmax for a ragged batch). */
+int gccnmf_klnmf_chain_status(const float* workspace, int F, int N, int K, int batch, int* status);
+
 /* Which launches gccnmf_klnmf uses for this problem under the current tuning: bit 0 = the direct latency kernels (a handful of files),
  * bit 1 = K1 + K2 as one launch of column tiles (tuning key 16), bit 2 = K3 + K4a as one launch of 64-bin slabs (key 17), bit 3 = the whole
  * call as one chained launch (key 21).  -1 on bad arguments.

@@ -775,6 +775,9 @@ def _klnmf_run(lib, V, W0, H0, F, N, K, B, iters, flags=0):
     ws = torch.zeros(lib.gccnmf_klnmf_workspace_floats(F, N, K, B), dtype=torch.float32, device='cuda')
     assert lib.gccnmf_klnmf(dV.data_ptr(), dW.data_ptr(), dH.data_ptr(), ws.data_ptr(), F, N, K, B, iters, 0.0, 1e-16, flags, stream()) == 0
     torch.cuda.synchronize()
+    import ctypes
+    st = ctypes.c_int(-1)
+    assert lib.gccnmf_klnmf_chain_status(ws.data_ptr(), F, N, K, B, ctypes.byref(st)) == 0 and st.value == 0      # every hand-over clean, one XCC per list
     return dW, dH
 
 

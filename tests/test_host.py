@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(flavor):
         pytest.skip('libgccnmf_hip_exp.so has not been built (make -C gcc_nmf_amd/csrc EXPERIMENTS=1)')
     names = declared_functions(experiments=(flavor == 'experiments'))
     product = declared_functions()
-    assert 40 <= len(product) <= 45, 'the product header is meant to shrink, not grow (round 6 added three: gccnmf_magnitude, gccnmf_klnmf_ragged + its workspace size)'
+    assert 40 <= len(product) <= 46, 'the product header is meant to shrink, not grow (round 6 added four: gccnmf_magnitude, gccnmf_klnmf_ragged + its workspace size, gccnmf_klnmf_chain_status)'
     handle = ctypes.CDLL(path)
     for n in names:
         assert hasattr(handle, n), n
