@@ -1207,7 +1207,7 @@ int gccnmf_short_chain_launch(ShortChainArgs a, hipStream_t stream) {
     if ((long)8 * a.first[3] * a.iterations > (1L << 30)) return GCCNMF_ERR_ARG;
     a.trace = gccnmf_trace_buf;
     a.trace_rows = gccnmf_trace_buf ? gccnmf_trace_blocks : 0;
-    a.trace_it = a.it0 + a.iterations - 1;
+    a.trace_it = a.it0 + (a.iterations > 4 ? a.iterations - 3 : a.iterations - 1);      // (timeline builds: a steady-state iteration, not the call's last)
     const int grid = 8 * a.first[3] * a.iterations;
     const unsigned pad = a.solo ? 24576u : 0u;                     // (lab: one workgroup per CU)
     const int kb = gccnmf_ceil_div(a.a12.Kd, 32);

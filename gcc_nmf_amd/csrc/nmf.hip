@@ -909,7 +909,7 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     if (iterations > 1 && stages != 4) return GCCNMF_ERR_ARG;
     if (it0 == 0 && iterations == 1) ch.sync[0].wait_cnt = nullptr;      // (nothing to wait for: the counters were just zeroed)
     ch.it0 = it0; ch.iterations = iterations;
-    ch.trace_it = it0 + iterations - 1;
+    ch.trace_it = it0 + (iterations > 4 ? iterations - 3 : iterations - 1);      // timeline builds: an iteration in the steady state of a whole-call launch, not its last
     if ((long)8 * ch.first[4] * iterations > (1L << 30)) return GCCNMF_ERR_ARG;
     for (int i = 0; i < stages; ++i) {           // timeline builds (gccnmf_debug_set_trace): stage i's item t of list x -> row 8 * (first[i] + t) + x
         a[i].trace = gccnmf_trace_buf ? gccnmf_trace_buf + 8L * 8 * ch.first[i] : nullptr;

@@ -106,7 +106,7 @@ def main():
     torch.cuda.synchronize()
     trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
     lib.gccnmf_debug_set_trace(_ptr(trace), nblk)
-    klnmf(4)                              # per-iteration launches overwrite the rows: the LAST iteration stays (the whole-call launch traces its last iteration)
+    klnmf(8)                              # per-iteration launches overwrite the rows: the LAST iteration stays; the whole-call launch traces its third-from-last
     torch.cuda.synchronize()
     lib.gccnmf_debug_set_trace(None, 0)
     lib.gccnmf_set_tuning(21, 0)

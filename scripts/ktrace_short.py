@@ -51,7 +51,7 @@ def main():
     torch.cuda.synchronize()
     trace = torch.zeros((nblk, 8), dtype=torch.int64, device=dev)
     lib.gccnmf_debug_set_trace(_ptr(trace), nblk)
-    klnmf(6)                                  # the launch traces its LAST iteration
+    klnmf(8)                                  # the launch traces its third-from-last iteration: steady state
     torch.cuda.synchronize()
     lib.gccnmf_debug_set_trace(None, 0)
     lib.gccnmf_set_tuning(21, 1)
@@ -65,7 +65,7 @@ def main():
     arrive, start, end = (rows[:, 7] - t0) / 100.0, (rows[:, 0] - t0) / 100.0, (rows[:, 3] - t0) / 100.0
     cu = rows[:, 4] >> 8
     names = ['K1+K2 column tiles', 'K3+K4a bin slabs', 'W update']
-    print('short-dictionary chain, K = %d, %d files: last iteration of 6, %d workgroups on %d CUs, span %.1f us' % (K, B, len(rows), len(np.unique(cu)), end.max()))
+    print('short-dictionary chain, K = %d, %d files: a steady-state iteration (6th of 8), %d workgroups on %d CUs, span %.1f us' % (K, B, len(rows), len(np.unique(cu)), end.max()))
     for s in range(3):
         m = stage_of == s
         print('  %-20s %5d items  arrive %6.1f .. %6.1f  end %6.1f us | waited: median %.1f p90 %.1f max %.1f, sum %.0f us | ran: median %.1f p90 %.1f us' % (
