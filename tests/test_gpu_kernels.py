@@ -480,7 +480,7 @@ def test_klnmf_short_dictionary_fused_launches(hip, F, T, K, B, alpha):
             assert lib.gccnmf_set_tuning(16, k16) == 0 and lib.gccnmf_set_tuning(17, k17) == 0
             b = len(files)
             if F == 513:                                       # the library reports the launches it will use
-                assert lib.gccnmf_klnmf_plan(F, N, K, b, 0) == ((2 if k16 else 0) | (4 if k17 else 0) if K <= 128 else 0), name
+                assert lib.gccnmf_klnmf_plan(F, N, K, b, 0) & 7 == ((2 if k16 else 0) | (4 if k17 else 0) if K <= 128 else 0), name      # (bit 3: chained, by rule or forced)
             Vd = padded(V[files], (b, g.Fp, g.Np), 'cuda')
             Wd = padded(np.repeat(W0[None], b, 0), (b, g.Fp, g.Kp), 'cuda')
             Hd = padded(np.repeat(H0[None], b, 0), (b, g.Kp, g.Np), 'cuda')
