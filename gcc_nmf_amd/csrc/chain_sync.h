@@ -30,6 +30,8 @@ struct GemmSync {
     int prod_narrow;
     int wait_scale_tiles;                // per-file counter of a ragged batch: wait_need is the count per COLUMN TILE of the file (x its own number of tiles)
     int wait_lag;                        // 0: the producer runs in the same iteration (waits for need x (it + 1)); 1: in the previous one (need x it: K4 -> K1)
+    int wide;                            // 1: producer and consumer may sit on DIFFERENT XCDs (a file's tiles spread over the lists): the producer writes its
+                                         //    XCD's L2 back (buffer_wbl2 sc1) before it signals -- the agent-scope release; the consumer's buffer_inv sc1 is the acquire
     unsigned* error;
     unsigned* xcc_seen;                  // [list]: bit x set by every workgroup of the list that ran on XCC x -- checked after the call (one bit per list)
 };
@@ -80,6 +82,7 @@ __device__ __forceinline__ void gemm_sync_signal(const GemmSync& y, int file, in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+            if (y.wide) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
             unsigned* c = y.sig_cnt + (long)file * y.sig_stride + (y.sig_per_tile ? (col0 >> 6) : 0);
             const unsigned n = y.sig_per_tile ? (unsigned)nw : 1u;
             asm volatile("global_atomic_add %0, %1, off sc1" : : "v"(c), "v"(n) : "memory");

@@ -54,8 +54,9 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //   21   chain             1   0,1,2,4,8 batch scale, K > 256: 1 = the whole gccnmf_klnmf call as ONE chained launch (gemm_dma.h: GemmSync) where it wins (>= 3 files per
 //                                        XCD, balanced whole-file lists, no other file group beside it); 0 = never; forced forms: 2 = K1 | K2, 4 = the four GEMMs of
 //                                        an iteration, 8 = every iteration of the call
-//   23   chain_rag         1     0..1    chained launches on whole-file lists: list x = files x, x + 8, ..., a file's ragged tiles behind its wide ones; any batch >= 13
-//                                        (0: the plain launch's lists -- equal eighths, short items last -- batch a multiple of 8 only)
+//   23   chain_lists       1     0..3    lists of a chained launch: 1 = by rule -- whole files per XCD (hand-over through that XCD's L2) where they balance, else the
+//                                        file-major tile list in equal eighths with agent-scope hand-over (a file may straddle XCDs); 0 = the plain launch's lists
+//                                        (batch a multiple of 8); 2 = always spread; 3 = always whole files
 //   24   chain_chunk     2048   1..65536 iterations per chained launch: a call of more iterations runs as several chained launches (the counters keep counting)
 //    1 X ablate            0             timing ablations of the register-staged kernel (results invalid)
 //    4 X ring              1     0..1    0 = small-batch tiles on the register-staged kernel instead of the LDS-DMA ring kernel

@@ -444,6 +444,25 @@ __host__ __device__ __forceinline__ bool gemm_dma_item(const GemmArgs& p, int li
         return false;
     }
     const int wt = p.tiles_m * p.wide_n;                      // wide tiles per file
+    if (p.whole_files == 2) {
+        // chained launches with agent-scope hand-over: the same file-major order (a file's wide tiles, then its ragged items), cut into equal eighths --
+        // a file may straddle two lists, any batch size balances
+        const int per = p.tiles_m * p.tiles_n;
+        const long idx = (long)list * p.cw + t;
+        if (t >= p.cw || idx >= (long)p.batch * per) return false;
+        const int q = (int)(idx / per), w = (int)(idx - (long)q * per);
+        if (w < wt) {
+            tm = w / p.wide_n;
+            col0 = (w - tm * p.wide_n) * 64;
+            nw = 2;
+        } else {
+            tm = w - wt;
+            col0 = (p.tiles_n - 1) * 64;
+            nw = 1;
+        }
+        file = gemm_dma_list_file(p, q) + p.file0;
+        return true;
+    }
     if (p.whole_files) {
         // chained launches: every producer and consumer of a file must run on ONE XCD in every GEMM of the iteration, whatever the batch
         // size: list x holds the files x, x + 8, ... whole, each file's tm-major wide tiles followed by its ragged items.  (A plain
@@ -1111,7 +1130,7 @@ unsigned* gccnmf_ticket_block(hipStream_t stream);
 //   when the launch shares the chip with another file group's launches (its early finish is used at once), or when the extra items do not
 //   cost the launch another round of workgroup slots (51 files: 128 tiles per XCD fit two rounds of 64, 122 + 7 items do not) | 2 (tests):
 //   every tile as two narrow halves
-static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM, bool whole_files = false) {
+static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM, int whole_files = 0) {
     a.tiles_m = gccnmf_ceil_div(a.M, 128 * TM);
     a.tiles_n = gccnmf_ceil_div(a.N, 64);
     a.lists = (a.xcd_affine && a.batch >= 8) ? 8 : 1;
@@ -1133,8 +1152,8 @@ static int gemm_dma_plan(GemmArgs& a, bool narrow_capable, int TM, bool whole_fi
         if (a.lists != 8 || policy > 1) return -1;
         a.rag = (narrow_ok && a.tiles_n >= 2 && a.N - (a.tiles_n - 1) * 64 <= 32) ? 1 : 0;      // (no round-count argument: nothing ends at a launch boundary)
         a.wide_n = a.tiles_n - a.rag;
-        a.whole_files = 1;
-        a.cw = ((a.batch + 7) / 8) * a.tiles_m * a.tiles_n;
+        a.whole_files = whole_files;
+        a.cw = whole_files == 2 ? (int)((tiles + 7) / 8) : ((a.batch + 7) / 8) * a.tiles_m * a.tiles_n;
         a.cr = a.split = 0;
         return a.lists * a.cw;
     }

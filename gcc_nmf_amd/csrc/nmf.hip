@@ -57,7 +57,8 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {1, 0, 8, 0},                       // 21 chain: 1 = the whole call as one chained launch where the rule in chain_stages says so; 0 off; forced forms (tests, A/B):
                                         //    2 = K1 | K2, 4 = K1 | K2 | K3 | K4 per iteration, 8 = every iteration of the call
     {0, 0, 1, 1},                       // 22 chain_solo: chained launches with one workgroup per CU (the freedom-from-deadlock test)
-    {1, 0, 1, 0},                       // 23 chain_rag: chained launches on whole-file lists (0: the plain launch's lists, batch a multiple of 8 only)
+    {1, 0, 3, 0},                       // 23 chain_lists: 1 by rule (whole files per XCD where they balance, else spread) | 0 the plain launch's lists (batch a multiple of 8) |
+                                        //    2 always spread: file-major equal eighths, agent-scope hand-over | 3 always whole files
     {2048, 1, 65536, 0},                // 24 chain_chunk: iterations per chained launch (a call of more iterations is several launches; tests use small values)
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
@@ -771,12 +772,29 @@ static long klnmf_workspace_base_floats(const NmfGeom& g, int batch) {
 // file's tiles on ONE XCD in every stage (batch a multiple of 8: list x holds the files x, x + 8, ... in all four GEMMs).
 static bool chain_capable(const NmfGeom& g, int batch, int flags, bool any_size = false);
 static bool chain_rule(int batch, int flags);
+// The lists of a chained launch (tuning key 23): 1 = whole files per XCD (hand-over through that XCD's L2), 2 = the file-major tile list cut into equal
+// eighths (a file may straddle XCDs: agent-scope hand-over, the producer writes its L2 back before it signals), 0 = the plain launch's lists.
+// By rule (key 23 = 1): whole files where they balance -- the longest list at most 2.7 % above the mean, i.e. multiples of 8 and e.g. 102 files -- else the
+// spread lists.  Same box (profiles/r06y_files_sweep_*.txt, iteration as a fraction of peak, whole | spread): 64 files 0.845 | 0.830 (the write-back costs
+// 1.7 %), 24: 0.774 | 0.761, 32: 0.840 | 0.826, 40: 0.849 | 0.832; 26: plain 0.698 | spread 0.786, 51: plain 0.781 | 0.826, 52: whole 0.795 | 0.826,
+// 77: 0.826 | 0.829, 25: plain 0.763 | 0.774, 20: plain 0.642 | 0.685; 16 files: plain 0.747, chained 0.584 -- the four stages of two files per XCD
+// cannot fill 64 slots, spread or not.
+static int chain_list_mode(int batch) {
+    const int key = gccnmf_tune_chain_rag;
+    if (key == 0 || key == 2) return key;
+    if (key == 3) return 1;
+    const int longest = (batch + 7) / 8;
+    return 1000L * 8 * longest <= 1027L * batch ? 1 : 2;
+}
 static int chain_stages(const NmfGeom& g, int batch, int flags) {
     const int want = gccnmf_tune_chain;
-    if (!want || !chain_capable(g, batch, flags) || ((batch & 7) && !gccnmf_tune_chain_rag)) return 0;
+    if (!want || !chain_capable(g, batch, flags) || ((batch & 7) && chain_list_mode(batch) == 0)) return 0;
     if (gccnmf_tune_tile_policy != 1 && (long)batch * gccnmf_ceil_div(g.N, 64) < 256) return 0;      // (the small-batch tile's territory)
     if (want != 1) return want;                                   // a forced form
-    return chain_rule(batch, flags) ? 8 : 0;
+    // by rule: not beside another file group's launches (two chained launches that share the chip are slower than two plain ones: 155 k against 158 k
+    // frames/s end to end); whole-file lists from three files per XCD on, spread lists from 20 files on
+    if (flags & 4) return 0;
+    return batch >= (chain_list_mode(batch) == 1 ? 24 : 20) ? 8 : 0;
 }
 // the shape and tuning conditions of any chained launch: the four GEMMs all on full-height LDS-DMA throughput tiles (K2 half-height up to 256 atoms)
 // with one XCD-affine list per XCD
@@ -853,7 +871,7 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
         if (i < stages) {
             // whole-file lists (key 23, default): any batch size, K4 never waits for a ragged K3 item at the end of a list
             const int tm = (i == 1 && tm1 == 2) ? 2 : 4;
-            int grid = gemm_dma_plan(a[i], i != 3 && tm == 4, tm, gccnmf_tune_chain_rag != 0 || rg != nullptr);
+            int grid = gemm_dma_plan(a[i], i != 3 && tm == 4, tm, rg ? 1 : chain_list_mode(batch));      // 0: the plain launch's lists | 1: whole files | 2: file-major equal eighths
             if (grid < 8 || a[i].lists != 8 || a[i].split) return GCCNMF_ERR_ARG;
             if (rg) {
                 // per list: the sum over its files of tiles_m x the file's own column tiles (K4: the uniform atom tiles, the file's own reduction length)
@@ -879,9 +897,11 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     unsigned* c34 = c23 + (long)batch * tn;
     unsigned* c41 = c34 + batch;
     unsigned* err = c41 + batch;
+    const bool wide = !rg && chain_list_mode(batch) == 2;          // a file's tiles spread over the XCDs: agent-scope hand-over, no XCC check
     for (int i = 0; i < 4; ++i) {
         ch.sync[i].error = err;
-        ch.sync[i].xcc_seen = err + 16;
+        ch.sync[i].xcc_seen = wide ? nullptr : err + 16;
+        ch.sync[i].wide = wide ? 1 : 0;
     }
     // does a producer run a file's ragged last column tile as ONE narrow item?  (a uniform batch: decided for the launch; a ragged one: per file)
     auto narrow_items = [&](int i) { return rg ? a[i].narrow_ok : (a[i].rag ? 1 : 0); };

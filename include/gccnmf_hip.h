@@ -66,7 +66,8 @@ int gccnmf_version(void);
  *      workgroups hand tiles over through ready counters in their XCD's L2 (csrc/gemm_dma.h: GemmSync), where that wins: at least three files
  *      per XCD, balanced whole-file lists, no other file group beside it; 0 = never; forced forms for tests and A/B runs: 2 = K1 | K2, 4 = the
  *      four GEMMs of an iteration, 8 = every iteration of the call.  Bitwise the same factors in every form.
- *  23  1 (default) = chained launches on whole-file lists (any batch size); 0 = on the plain launch's lists (batch a multiple of 8)
+ *  23  lists of a chained launch: 1 (default) = whole files per XCD where they balance, else the tile list in equal eighths with agent-scope hand-over;
+ *      0 = the plain launch's lists (batch a multiple of 8); 2 = always spread; 3 = always whole files
  *  24  iterations per chained launch (default 2048; a call of more iterations is several chained launches)
  *   X  1 ablations of the register-staged kernel (results INVALID), 4 ring kernel off, 5 / 6 parts of the round-3 single-file split-K, 11 / 13
  *      fixed tile / pipeline depth of the direct kernels, 14 short H updates off the ring kernel, 15 one FFT stage per LDS round trip, 18 / 19

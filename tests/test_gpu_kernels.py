@@ -800,6 +800,12 @@ def test_chained_iteration_is_bitwise_the_four_launches(hip, B, T, K, iters):
             res[chain] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
             if chain:
                 res[(chain, 'again')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        # a file's tiles spread over the XCD lists (file-major equal eighths), handed over at agent scope (key 23 = 2)
+        assert lib.gccnmf_set_tuning(23, 2) == 0 and lib.gccnmf_set_tuning(21, 8) == 0
+        res[(8, 'spread lists')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        assert lib.gccnmf_set_tuning(23, 3) == 0                  # whole files per XCD at any batch size (by rule only where they balance)
+        res[(8, 'whole files')] = _klnmf_run(lib, V, W0, H0, F, N, K, B, iters)
+        assert lib.gccnmf_set_tuning(23, 1) == 0
         # batch a multiple of 8: also on the plain launch's lists (key 23 = 0)
         if B % 8 == 0:
             assert lib.gccnmf_set_tuning(23, 0) == 0 and lib.gccnmf_set_tuning(21, 8) == 0

@@ -201,9 +201,9 @@ def test_klnmf_plan_is_a_pure_function_of_shape_batch_and_tuning():
     lib = _hip.lib()
     plan = lib.gccnmf_klnmf_plan
     assert plan(513, 1244, 1024, 1, 0) == 1 and plan(513, 1244, 1024, 4, 0) == 1 and plan(513, 1244, 1024, 64, 0) == 8     # direct path: up to 4 files
-    # bit 3: the whole call as one chained launch -- K > 256, at least three files per XCD, the longest whole-file list at most 8 % above
-    # the mean, no other file group beside it (round 6, profiles/r06h_files_sweep_*.txt)
-    assert [plan(513, 1244, 1024, b, 0) for b in (16, 24, 25, 26, 32, 51, 52, 77, 104)] == [0, 8, 0, 0, 8, 0, 8, 8, 8]
+    # bit 3: the whole call as one chained launch -- K >= 256 a multiple of 128, from 20 files on (whole-file lists where they balance: from 24 files;
+    # else the tile list in equal eighths with agent-scope hand-over), no other file group beside it (round 6, profiles/r06y_files_sweep_*.txt)
+    assert [plan(513, 1244, 1024, b, 0) for b in (16, 19, 20, 24, 25, 26, 32, 51, 52, 77, 104)] == [0, 0, 8, 8, 8, 8, 8, 8, 8, 8, 8]
     assert plan(513, 1244, 1024, 32, 4 | (2 << 8)) == 0 and plan(513, 1244, 256, 64, 0) == 8 and plan(513, 1244, 320, 64, 0) == 0 and plan(513, 1244, 384, 64, 0) == 8
     assert plan(513, 1244, 1024, 64, 1) == 0 and plan(513, 1244, 1024, 64, 2) == 0              # no XCD-affine lists / unfused W update: plain launches
     try:
