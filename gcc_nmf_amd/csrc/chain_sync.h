@@ -32,6 +32,7 @@ struct GemmSync {
     int wait_lag;                        // 0: the producer runs in the same iteration (waits for need x (it + 1)); 1: in the previous one (need x it: K4 -> K1)
     int wide;                            // 1: producer and consumer may sit on DIFFERENT XCDs (a file's tiles spread over the lists): the producer writes its
                                          //    XCD's L2 back (buffer_wbl2 sc1) before it signals -- the agent-scope release; the consumer's buffer_inv sc1 is the acquire
+    long long timeout;                   // s_memrealtime ticks a consumer polls before it gives up (GEMM_SYNC_TIMEOUT; the lab build's fault injection: 0)
     unsigned* error;
     unsigned* xcc_seen;                  // [list]: bit x set by every workgroup of the list that ran on XCC x -- checked after the call (one bit per list)
 };
@@ -66,7 +67,7 @@ __device__ __forceinline__ void gemm_sync_wait(const GemmSync& y, int file, int 
             const long long t0 = __builtin_amdgcn_s_memrealtime();
             while (gemm_sync_peek(c) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > GEMM_SYNC_TIMEOUT) {
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > y.timeout) {
                     *y.error = 1u;
                     break;
                 }

@@ -69,8 +69,9 @@ static inline GccNmfPitches gccnmf_make_pitches(int F, int T, int K) {
 //   18 X persistent        0     0..1    1 = launches of more than 512 tiles as 512 resident workgroups pulling tiles by ticket
 //   19 X prefetch          1     0..1    1 = a resident workgroup requests its next tile's first k-tile before the current epilogue
 //   20 X wide_update_w     1     0..1    0 = the one-pass W update of short dictionaries at batch scale on 16 atoms per workgroup (round 4)
+//   25 X chain_fault       0     0..1    1 = fault injection: a consumer of a chained launch that has to wait gives up at once (error flag -> NaN factors -> the engine's fallback)
 //   22 X chain_solo        0     0..1    1 = chained launches reserve enough LDS that only ONE workgroup fits a CU (in-order dispatch => no deadlock: tested)
-#define GCCNMF_TUNE_KEYS 25
+#define GCCNMF_TUNE_KEYS 26
 struct GccNmfTune {
     int v[GCCNMF_TUNE_KEYS];
 };
@@ -104,3 +105,4 @@ struct GccNmfCall {
 #define gccnmf_tune_chain_solo (gccnmf_tune.v[22])
 #define gccnmf_tune_chain_rag (gccnmf_tune.v[23])
 #define gccnmf_tune_chain_chunk (gccnmf_tune.v[24])
+#define gccnmf_tune_chain_fault (gccnmf_tune.v[25])

@@ -80,6 +80,7 @@ struct ShortChainArgs {
     unsigned* counters;          // [3][batch] ready counters (zeroed by the caller), then the error flag / XCC table block of the throughput chain
     unsigned* error;
     unsigned* xcc_seen;
+    long long timeout;           // GemmSync.timeout of every stage
     long long* trace;
     int trace_rows, trace_it;
 };

@@ -1165,6 +1165,7 @@ __global__ __launch_bounds__(256, 2) void gccnmf_short_chain_kernel(const ShortC
     // stage s waits for the per-file counter of stage s - 1 (stage 0: for the W update of the PREVIOUS iteration) and signals its own
     GemmSync y = {};
     y.error = c.error;
+    y.timeout = c.timeout;
     y.xcc_seen = c.xcc_seen;
     y.sig_cnt = c.counters + stage * batch;
     y.sig_stride = 1;

@@ -60,6 +60,7 @@ static const GccNmfKnob gccnmf_knobs[GCCNMF_TUNE_KEYS] = {
     {1, 0, 3, 0},                       // 23 chain_lists: 1 by rule (whole files per XCD where they balance, else spread) | 0 the plain launch's lists (batch a multiple of 8) |
                                         //    2 always spread: file-major equal eighths, agent-scope hand-over | 3 always whole files
     {2048, 1, 65536, 0},                // 24 chain_chunk: iterations per chained launch (a call of more iterations is several launches; tests use small values)
+    {0, 0, 1, 1},                       // 25 chain_fault: fault injection -- consumers of chained launches give up waiting at once (the failure path's test)
 };
 static std::atomic<int> gccnmf_knob_value[GCCNMF_TUNE_KEYS];
 static std::atomic<int> gccnmf_knobs_ready{0};
@@ -900,6 +901,7 @@ static int launch_klnmf_chain(int stages, const NmfGeom& g, const float* V, floa
     const bool wide = !rg && chain_list_mode(batch) == 2;          // a file's tiles spread over the XCDs: agent-scope hand-over, no XCC check
     for (int i = 0; i < 4; ++i) {
         ch.sync[i].error = err;
+        ch.sync[i].timeout = gccnmf_tune_chain_fault ? 0 : GEMM_SYNC_TIMEOUT;      // (lab build, key 25: every consumer that has to wait gives up at once)
         ch.sync[i].xcc_seen = wide ? nullptr : err + 16;
         ch.sync[i].wide = wide ? 1 : 0;
     }
@@ -983,6 +985,7 @@ static int launch_short_chain(const NmfGeom& g, const float* V, float* W, float*
     c.counters = counters;
     c.error = counters + chain_counter_floats(g, batch) - 32;
     c.xcc_seen = c.error + 16;
+    c.timeout = gccnmf_tune_chain_fault ? 0 : GEMM_SYNC_TIMEOUT;
     return gccnmf_short_chain_launch(c, s);
 }
 
@@ -1136,6 +1139,8 @@ int gccnmf_klnmf(const float* V, float* W, float* H, float* workspace, int F, in
     const int chained = chain_stages(g, batch, flags);          // 0 | 2: K1 | K2 in one launch | 4: the whole iteration | 8: the whole call
     unsigned* counters = (unsigned*)(workspace + klnmf_workspace_base_floats(g, batch));
     const int short_group = chained ? 0 : short_chain_group(g, batch, flags);      // K <= 128: the three launches of every iteration as one chained launch
+    // the status words describe THIS call (gccnmf_klnmf_chain_status): a call that does not chain clears what an earlier, chained one may have left
+    if (!chained && !short_group && hipMemsetAsync(counters + chain_counter_floats(g, batch) - 32, 0, 32 * sizeof(unsigned), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
     if (short_group && iterations > 0) {
         if (hipMemsetAsync(counters, 0, sizeof(unsigned) * chain_counter_floats(g, batch), s) != hipSuccess) return GCCNMF_ERR_LAUNCH;
         float* R0 = workspace;

@@ -345,6 +345,14 @@ class GCCNMFEngine(object):
         self.pcm_in = None
         self.x.copy_(hx, non_blocking=True)
         self.run()
+        if self.chain_failed():
+            # The chained KL-NMF launch did not hand over cleanly (a consumer timed out / a work list ran on more than one XCC): its factors are
+            # NaN by construction.  Do not fail the batch: switch this process to the plain launches and run the stages behind the STFT again.
+            import warnings
+            warnings.warn('gcc_nmf_amd: a chained KL-NMF launch did not hand over cleanly; this process falls back to the plain launches '
+                          '(gccnmf_set_tuning(21, 0)) and repeats the batch', RuntimeWarning)
+            _hip.check(self.lib.gccnmf_set_tuning(21, 0), 'gccnmf_set_tuning')
+            self.run(stft=False)
         hy.copy_(self.y, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         self.check_status()
@@ -441,6 +449,19 @@ class GCCNMFEngine(object):
         st = self.status.cpu().numpy()
         if st.any():
             raise ValueError('fewer than %d angular-spectrum peaks in file(s) %s' % (self.g.S, np.nonzero(st)[0].tolist()))
+
+    @_on_device
+    def chain_failed(self):
+        """Status word of the last chained KL-NMF launch(es) of this engine (0 = clean or not chained); synchronises the stream."""
+        import ctypes
+        g, st, worst = self.g, ctypes.c_int(0), 0
+        per = self.batch // self.nmf_groups
+        ws_per = self.ws_nmf.numel() // self.nmf_groups
+        torch.cuda.current_stream(self.device).synchronize()
+        for i in range(self.nmf_groups):
+            _hip.check(self.lib.gccnmf_klnmf_chain_status(_ptr(self.ws_nmf[i * ws_per:]), g.F, g.N, g.K, per, ctypes.byref(st)), 'gccnmf_klnmf_chain_status')
+            worst |= st.value
+        return worst
 
     @_on_device
     def check_chain_status(self):

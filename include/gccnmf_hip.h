@@ -71,7 +71,8 @@ int gccnmf_version(void);
  *  24  iterations per chained launch (default 2048; a call of more iterations is several chained launches)
  *   X  1 ablations of the register-staged kernel (results INVALID), 4 ring kernel off, 5 / 6 parts of the round-3 single-file split-K, 11 / 13
  *      fixed tile / pipeline depth of the direct kernels, 14 short H updates off the ring kernel, 15 one FFT stage per LDS round trip, 18 / 19
- *      resident-workgroup grid and its prefetch, 20 the 16-atom W update, 22 chained launches with one workgroup per CU
+ *      resident-workgroup grid and its prefetch, 20 the 16-atom W update, 22 chained launches with one workgroup per CU, 25 fault injection into
+ *      the chained launches' hand-over (consumers give up at once)
  * gccnmf_klnmf_plan reports what a call would launch.  Unknown keys / values: GCCNMF_ERR_ARG. */
 int gccnmf_set_tuning(int key, int value);
 

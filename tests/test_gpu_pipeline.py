@@ -562,3 +562,35 @@ def test_ragged_batch_is_bitwise_the_equal_length_batches(K, iters, expect_ragge
     assert sub.get_tdoa_indexes()[k].tolist() == r['idx']
     assert rel(sub.get_WH()[0][k], r['W']) < 1e-4 and rel(sub.get_WH()[1][k], r['H']) < 1e-4
     assert np.sqrt(np.mean((ys[0].astype(np.float64) - r['y']) ** 2)) < 1e-5
+
+
+def test_a_failed_chained_launch_is_loud_and_the_engine_falls_back():
+    """Fault injection (lab build, tuning key 25): every consumer of a chained launch that has to wait gives up at once.  The library flags it, turns
+    the factors into NaN (never plausible garbage) and reports it (gccnmf_klnmf_chain_status); GCCNMFEngine.separate() then switches the process to
+    the plain launches, repeats the batch with a warning, and returns exactly the plain result; an explicit check raises."""
+    from gcc_nmf_amd import _hip, HipLibraryError
+    from gcc_nmf_amd.synthetic import synthetic_batch
+    lib = _hip.lib()
+    if lib.gccnmf_set_tuning(25, 1) != 0:
+        pytest.skip('key 25 (fault injection into the chained hand-over) exists in experiment builds only: make EXPERIMENTS=1')
+    xs = synthetic_batch(800, 24, numSamples=96000)
+    try:
+        assert lib.gccnmf_set_tuning(25, 0) == 0 and lib.gccnmf_set_tuning(21, 0) == 0
+        e = engine(96000, dictionarySize=1024, numIterations=5, batch=24)
+        y_plain = e.separate(xs)
+        assert lib.gccnmf_set_tuning(21, 8) == 0 and lib.gccnmf_set_tuning(25, 1) == 0
+        e = engine(96000, dictionarySize=1024, numIterations=5, batch=24)
+        assert e.lib.gccnmf_klnmf_plan(e.g.F, e.g.N, 1024, 24, 0) & 8
+        e.upload(xs)
+        e.run()
+        assert e.chain_failed() & 1
+        assert torch.isnan(e.W).all() and torch.isnan(e.H).all()
+        with pytest.raises(HipLibraryError, match='did not hand over cleanly'):
+            e.check_status()
+        with pytest.warns(RuntimeWarning, match='falls back to the plain launches'):
+            y = e.separate(xs)
+        assert np.array_equal(y, y_plain)
+        assert lib.gccnmf_klnmf_plan(e.g.F, e.g.N, 1024, 24, 0) & 8 == 0          # the process now runs plain launches
+    finally:
+        lib.gccnmf_set_tuning(25, 0)
+        lib.gccnmf_set_tuning(21, 1)
