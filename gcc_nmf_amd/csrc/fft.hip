@@ -183,23 +183,38 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 // in ASCENDING frame order, every sample starting from 0 -- the order librosaSTFT.py:275-281 accumulates in; the result is bit for
 // bit that of istft_frames_kernel + istft_ola_kernel (no fma contraction in this file, same accumulation).
 // grid = batch * (nsig/2) * ceil(T / G).
+// (lab build: shader clocks per phase of a workgroup -- hand-out / shift, spectrogram fetch + placement, butterflies, overlap-add -- into the trace
+// buffer of gccnmf_debug_set_trace, scripts/ktrace_istft.py; the product build carries none of it)
+#ifdef GCCNMF_EXPERIMENTS
+extern long long* gccnmf_trace_buf;
+extern int gccnmf_trace_blocks;
+#define ISTFT_TRACE_BEGIN() long long tr_acc[4] = {0, 0, 0, 0}, tr_t = 0, tr_t0 = 0; if (trace && threadIdx.x == 0) { tr_t0 = __builtin_amdgcn_s_memrealtime(); tr_t = __builtin_amdgcn_s_memtime(); }
+#define ISTFT_TRACE(k) if (trace && threadIdx.x == 0) { const long long n_ = __builtin_amdgcn_s_memtime(); tr_acc[k] += n_ - tr_t; tr_t = n_; }
+#define ISTFT_TRACE_END() if (trace && threadIdx.x == 0) { long long* r_ = trace + 8L * blockIdx.x; r_[0] = tr_t0; r_[1] = tr_acc[0]; r_[2] = tr_acc[1]; r_[3] = tr_acc[2]; r_[4] = tr_acc[3]; r_[5] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define ISTFT_TRACE_BEGIN()
+#define ISTFT_TRACE(k)
+#define ISTFT_TRACE_END()
+#endif
 #ifndef ISTFT_TB
 #define ISTFT_TB 4
 #endif
 #ifndef ISTFT_SUB
 #define ISTFT_SUB 8
 #endif
-__global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int hop, int T,
+__global__ __launch_bounds__(FFT_NT, 2) void istft_fused_kernel(const float2* __restrict__ spec, int nsig, int N, int logN, int hop, int T,
                                                              const float* __restrict__ window, const float2* __restrict__ twiddle,
-                                                             int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y, int ps) {
+                                                             int F, int Fp, int Tp, int trim, int L, float gain, float* __restrict__ y, int ps, long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float2 fft_smem[];
     constexpr int TB = ISTFT_TB, G = ISTFT_TB * ISTFT_SUB;
+    ISTFT_TRACE_BEGIN();
     const int zstride = N + (N >> ps) + FFT_ZPAD;
     float2* z = fft_smem;
     float2* tw = fft_smem + TB * zstride;
     const int span = N + hop * (TB - 1);                  // samples one sub-batch touches
     float* acc_a = (float*)(tw + N / 2);                  // [span] per signal of the pair
     float* acc_b = acc_a + span;
+    float* s_win = acc_b + span;                          // [N] the synthesis window
     const int groups = (T + G - 1) / G, npairs = nsig / 2;
     int id = blockIdx.x;
     const int g = id % groups;
@@ -218,43 +233,61 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
     const float invN = 1.0f / (float)N;
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
+    for (int i = threadIdx.x; i < N; i += FFT_NT) s_win[i] = window[i];
     for (int i = threadIdx.x; i < 2 * span; i += FFT_NT) acc_a[i] = 0.f;
     long base = (long)t_first * hop;                      // untrimmed sample index of acc[0]
     for (int fs = t_first; fs < t_end; fs += TB) {
+        // (an opaque copy of the thread index per sub-batch: the unrolled phases below derive ~80 addresses from it, and as invariants of this loop they
+        // were hoisted in front of it and spilled -- 320 bytes of scratch, reloaded inside the loop)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         // samples before this sub-batch's first frame are final: hand them out, slide the accumulator
         const int shift = (int)((long)fs * hop - base);
         if (shift > 0) {
             __syncthreads();
-            float keep_a[8], keep_b[8];                   // span / FFT_NT <= 8 for N <= 2048
-            for (int i = threadIdx.x, r = 0; i < span; i += FFT_NT, ++r) {
-                const float va = acc_a[i], vb = acc_b[i];
-                if (i < shift) {
+            // (all LDS reads of the thread first -- clamped, masked afterwards; span <= 8 FFT_NT for n_fft <= 2048)
+            float out_a[8], out_b[8], keep_a[8], keep_b[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + r * FFT_NT;
+                const int ic = min(i, span - 1), is = min(i + shift, span - 1);
+                out_a[r] = acc_a[ic];
+                out_b[r] = acc_b[ic];
+                keep_a[r] = acc_a[is];
+                keep_b[r] = acc_b[is];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + r * FFT_NT;
+                if (i < shift && i < span) {
                     const long sg = base + i;
                     if (sg >= own_lo && sg < own_hi) {
                         const long m = sg - trim;
                         if (m >= 0 && m < L) {
-                            ya[m] = va * gain;
-                            yb[m] = vb * gain;
+                            ya[m] = out_a[r] * gain;
+                            yb[m] = out_b[r] * gain;
                         }
                     }
                 }
-                keep_a[r] = (i + shift < span) ? acc_a[i + shift] : 0.f;
-                keep_b[r] = (i + shift < span) ? acc_b[i + shift] : 0.f;
+                if (i + shift >= span) keep_a[r] = keep_b[r] = 0.f;
             }
             __syncthreads();
-            for (int i = threadIdx.x, r = 0; i < span; i += FFT_NT, ++r) {
-                acc_a[i] = keep_a[r];
-                acc_b[i] = keep_b[r];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = tid + r * FFT_NT;
+                if (i < span) {
+                    acc_a[i] = keep_a[r];
+                    acc_b[i] = keep_b[r];
+                }
             }
             base += shift;
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
-            const int f = idx / TB, tb = idx - f * TB;
-            const int t = fs + tb;
+        ISTFT_TRACE(0);
+        // bin f of frame row tb of the sub-batch: the pair's two spectra as ONE complex input, in bit-reversed order
+        auto place = [&](int f, int tb, bool valid, float2 sa, float2 sb) {
             float2 fa = make_float2(0.f, 0.f), fb = fa;
-            if (t < t_end) {
-                const float2 sa = Sa[(long)f * Tp + t], sb = Sb[(long)f * Tp + t];
+            if (valid) {
                 fa = make_float2(sa.x, -sa.y);   // istft undoes the stored conjugate (librosaSTFT.py:278)
                 fb = make_float2(sb.x, -sb.y);
             }
@@ -265,26 +298,76 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
             float2* zz = z + tb * zstride;
             zz[fft_pad(bitrev(f, logN), ps)] = make_float2(fa.x - fb.y, fa.y + fb.x);
             if (f != 0 && f != N / 2) zz[fft_pad(bitrev(N - f, logN), ps)] = make_float2(fa.x + fb.y, fb.x - fa.y);
-        }
-        __syncthreads();
-        fft_stages_any<true, TB>(z, tw, N, logN, zstride, ps);
-        // every thread owns the accumulator positions i = tid, tid + NT, ...: frames added in ascending order, no hazards
-        for (int i = threadIdx.x; i < span; i += FFT_NT) {
-            float va = acc_a[i], vb = acc_b[i];
+        };
+        // Every fetch of the thread is issued before the first placement (clamped addresses, masked afterwards: a conditional load ends a basic
+        // block and its wait).  Left as one loop, the compiler's code was fetch - wait - place per trip: nine dependent round trips to the memory
+        // side per sub-batch, 35 % of a workgroup's clocks (profiles/r06ah_ktrace_istft.txt).
+        constexpr int KI = (513 * TB + FFT_NT - 1) / FFT_NT;      // (bin, frame) items per thread, n_fft <= 1024
+        if (F * TB <= KI * FFT_NT) {
+            float2 va[KI], vb[KI];
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) {
-                const int n = i - tb * hop;
-                if (n >= 0 && n < N && fs + tb < t_end) {
-                    const float2 v = z[tb * zstride + fft_pad(n, ps)];
-                    const float w = window[n];
-                    // (no fma across the window product: this file is compiled with -ffp-contract=off; the reference adds whole frames)
-                    va = va + w * (v.x * invN);
-                    vb = vb + w * (v.y * invN);
+            for (int j = 0; j < KI; ++j) {
+                const int idx = min(tid + j * FFT_NT, F * TB - 1);
+                const int f = idx / TB, tb = idx - f * TB;
+                const long o = (long)f * Tp + min(fs + tb, t_end - 1);
+                va[j] = Sa[o];
+                vb[j] = Sb[o];
+            }
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const int idx = tid + j * FFT_NT;
+                if (idx < F * TB) {
+                    const int f = idx / TB, tb = idx - f * TB;
+                    place(f, tb, fs + tb < t_end, va[j], vb[j]);
                 }
             }
-            acc_a[i] = va;
-            acc_b[i] = vb;
+        } else {
+            for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
+                const int f = idx / TB, tb = idx - f * TB;
+                const int t = fs + tb;
+                float2 sa = make_float2(0.f, 0.f), sb = sa;
+                if (t < t_end) {
+                    sa = Sa[(long)f * Tp + t];
+                    sb = Sb[(long)f * Tp + t];
+                }
+                place(f, tb, t < t_end, sa, sb);
+            }
         }
+        __syncthreads();
+        ISTFT_TRACE(1);
+        fft_stages_any<true, TB>(z, tw, N, logN, zstride, ps);
+        ISTFT_TRACE(2);
+        // every thread owns the accumulator positions i = tid, tid + NT, ...: frames added in ascending order, no hazards.  Branch-free reads
+        // (clamped indexes, the window from LDS) so that the reads of all positions can be in flight together; the additions are masked.
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if ((r & 1) == 0) __builtin_amdgcn_sched_barrier(0);      // (two positions' reads at a time: all eight together spill)
+            const int i = tid + r * FFT_NT;
+            const int ic = min(i, span - 1);
+            float va = acc_a[ic], vb = acc_b[ic];
+            float2 v[TB];
+            float w[TB];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int nc = min(max(ic - tb * hop, 0), N - 1);
+                v[tb] = z[tb * zstride + fft_pad(nc, ps)];
+                w[tb] = s_win[nc];
+            }
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const int n = ic - tb * hop;
+                // (no fma across the window product: this file is compiled with -ffp-contract=off; the reference adds whole frames)
+                const float na = va + w[tb] * (v[tb].x * invN), nb = vb + w[tb] * (v[tb].y * invN);
+                const bool on = n >= 0 && n < N && fs + tb < t_end;
+                va = on ? na : va;
+                vb = on ? nb : vb;
+            }
+            if (i < span) {
+                acc_a[i] = va;
+                acc_b[i] = vb;
+            }
+        }
+        ISTFT_TRACE(3);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < span; i += FFT_NT) {
@@ -297,6 +380,8 @@ __global__ __launch_bounds__(FFT_NT) void istft_fused_kernel(const float2* __res
             }
         }
     }
+    ISTFT_TRACE(0);
+    ISTFT_TRACE_END();
 }
 
 // ---- int16 egress (gccNMF/wavfile.py:39-48, :92-131) ---------------------------------------------------------
@@ -333,6 +418,13 @@ __global__ __launch_bounds__(256) void pcm_pack_kernel(const float* __restrict__
     pcm[g * L + m] = make_short2((short)(int)a, (short)(int)b);
 }
 
+static inline long long* istft_trace(int grid) {
+#ifdef GCCNMF_EXPERIMENTS
+    return (gccnmf_trace_buf && grid <= gccnmf_trace_blocks) ? gccnmf_trace_buf : nullptr;
+#else
+    return nullptr;
+#endif
+}
 static inline int fft_ps() { return gccnmf_tune_fft_r16 ? 4 : FFT_NOPAD; }
 static inline size_t fft_rows_bytes(int tb, int n_fft, int ps) { return sizeof(float2) * ((size_t)tb * fft_row_floats2(n_fft, ps) + n_fft / 2); }
 
@@ -399,14 +491,14 @@ int gccnmf_istft_ola(const float* spec, int nsig, int n_fft, int hop, int T, int
         if (L < 1) return GCCNMF_ERR_ARG;
         const int span = n_fft + hop * (ISTFT_TB - 1);
         if (span > 8 * FFT_NT) return GCCNMF_ERR_UNSUPPORTED;          // hop > n_fft / 3 or so: use the two-kernel form
-        const size_t lds = fft_rows_bytes(ISTFT_TB, n_fft, ps) + sizeof(float) * 2 * span;
+        const size_t lds = fft_rows_bytes(ISTFT_TB, n_fft, ps) + sizeof(float) * (2 * span + n_fft);
         if (lds > 64 * 1024) {
             if (hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return GCCNMF_ERR_LAUNCH;
         }
         const int groups = gccnmf_ceil_div(T, ISTFT_TB * ISTFT_SUB);
         hipLaunchKernelGGL(istft_fused_kernel, dim3(batch * (nsig / 2) * groups), dim3(FFT_NT), lds, (hipStream_t)stream, (const float2*)spec,
-                           nsig, n_fft, logN, hop, T, window, (const float2*)twiddle, F, p.Fp, p.Tp, trim, L, gain, y, ps);
+                           nsig, n_fft, logN, hop, T, window, (const float2*)twiddle, F, p.Fp, p.Tp, trim, L, gain, y, ps, istft_trace(batch * (nsig / 2) * groups));
         GCCNMF_CHECK_LAUNCH();
         return GCCNMF_OK;
     }
