@@ -36,21 +36,38 @@ __global__ __launch_bounds__(FFT_NT) void stft_stereo_kernel(const float* __rest
     const short2* pcm = (const short2*)x + b * x_stride;      // PCM16: x_stride counts stereo frames
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
-    for (int idx = threadIdx.x; idx < TB * N; idx += FFT_NT) {
-        const int tb = idx / N, n = idx - tb * N;
-        const int t = t0 + tb;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < T) {
-            const float w = window[n];
-            const long s = (long)t * hop + n;
+    // Eight samples per thread at a time, every load before the first use (clamped addresses, masked afterwards): as one plain loop the
+    // compiler's code was load - wait - store per trip, TB N / 256 = 32 dependent round trips per workgroup.
+    constexpr int UN = 8;
+    for (int base = threadIdx.x; base < TB * N; base += FFT_NT * UN) {
+        float w[UN], xa[UN], xb[UN];
+        short2 q[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int idx = min(base + j * FFT_NT, TB * N - 1);
+            const int tb = idx / N, n = idx - tb * N;
+            const long s = (long)min(t0 + tb, T - 1) * hop + n;
+            w[j] = window[n];
             if (PCM16) {
-                const short2 q = pcm[s];
-                v = make_float2(w * ((float)q.x / 32768.f), w * ((float)q.y / 32768.f));
+                q[j] = pcm[s];
             } else {
-                v = make_float2(w * xl[s], w * xr[s]);
+                xa[j] = xl[s];
+                xb[j] = xr[s];
             }
         }
-        z[tb * zstride + fft_pad(bitrev(n, logN), ps)] = v;
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int idx = base + j * FFT_NT;
+            if (idx < TB * N) {
+                const int tb = idx / N, n = idx - tb * N;
+                float2 v = make_float2(0.f, 0.f);
+                if (t0 + tb < T) {
+                    if (PCM16) v = make_float2(w[j] * ((float)q[j].x / 32768.f), w[j] * ((float)q[j].y / 32768.f));
+                    else v = make_float2(w[j] * xa[j], w[j] * xb[j]);
+                }
+                z[tb * zstride + fft_pad(bitrev(n, logN), ps)] = v;
+            }
+        }
     }
     __syncthreads();
 #if !(FFT_ABL & 1)
