@@ -135,22 +135,37 @@ __global__ __launch_bounds__(FFT_NT) void istft_frames_kernel(const float2* __re
     const float2* Sb = Sa + plane;
 
     for (int i = threadIdx.x; i < N / 2; i += FFT_NT) tw[i] = twiddle[i];
-    for (int idx = threadIdx.x; idx < F * TB; idx += FFT_NT) {
-        const int f = idx / TB, tb = idx - f * TB;
-        const int t = t0 + tb;
-        float2 fa = make_float2(0.f, 0.f), fb = fa;
-        if (t < T) {
-            const float2 sa = Sa[(long)f * Tp + t], sb = Sb[(long)f * Tp + t];
-            fa = make_float2(sa.x, -sa.y);   // istft undoes the stored conjugate (librosaSTFT.py:278)
-            fb = make_float2(sb.x, -sb.y);
+    // (eight bins per thread at a time, every fetch before the first placement: see istft_fused_kernel)
+    constexpr int UN = 8;
+    for (int base = threadIdx.x; base < F * TB; base += FFT_NT * UN) {
+        float2 va[UN], vb[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int idx = min(base + j * FFT_NT, F * TB - 1);
+            const int f = idx / TB, tb = idx - f * TB;
+            const long o = (long)f * Tp + min(t0 + tb, T - 1);
+            va[j] = Sa[o];
+            vb[j] = Sb[o];
         }
-        if (f == 0 || f == N / 2) {          // ifft(...).real keeps only the real part of these two bins
-            fa.y = 0.f;
-            fb.y = 0.f;
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int idx = base + j * FFT_NT;
+            if (idx < F * TB) {
+                const int f = idx / TB, tb = idx - f * TB;
+                float2 fa = make_float2(0.f, 0.f), fb = fa;
+                if (t0 + tb < T) {
+                    fa = make_float2(va[j].x, -va[j].y);   // istft undoes the stored conjugate (librosaSTFT.py:278)
+                    fb = make_float2(vb[j].x, -vb[j].y);
+                }
+                if (f == 0 || f == N / 2) {          // ifft(...).real keeps only the real part of these two bins
+                    fa.y = 0.f;
+                    fb.y = 0.f;
+                }
+                float2* zz = z + tb * zstride;
+                zz[fft_pad(bitrev(f, logN), ps)] = make_float2(fa.x - fb.y, fa.y + fb.x);
+                if (f != 0 && f != N / 2) zz[fft_pad(bitrev(N - f, logN), ps)] = make_float2(fa.x + fb.y, fb.x - fa.y);
+            }
         }
-        float2* zz = z + tb * zstride;
-        zz[fft_pad(bitrev(f, logN), ps)] = make_float2(fa.x - fb.y, fa.y + fb.x);
-        if (f != 0 && f != N / 2) zz[fft_pad(bitrev(N - f, logN), ps)] = make_float2(fa.x + fb.y, fb.x - fa.y);
     }
     __syncthreads();
     fft_stages_any<true, TB>(z, tw, N, logN, zstride, ps);
