@@ -205,12 +205,21 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
             va[r] = V[ro + ca];
             vb[r] = V[ro + cb];
         }
+        // (the quotients outside the predicated stores: inside them every element's division sat behind a branch with a full
+        // `s_waitcnt vmcnt(0)` -- the previous element's store -- in front of it; an element that is not stored may divide by zero, harmlessly)
+        float qa[16], qb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            qa[r] = va[r] / acc_a[r];
+            qb[r] = vb[r] / acc_b[r];
+            asm volatile("" : "+v"(qa[r]), "+v"(qb[r]));      // (keeps the division from being sunk back into the store's branch)
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             if (row < p.M) {
-                if (ok_a) C[(long)row * p.ldc + col_a] = va[r] / acc_a[r];
-                if (ok_b) C[(long)row * p.ldc + col_b] = vb[r] / acc_b[r];
+                if (ok_a) C[(long)row * p.ldc + col_a] = qa[r];
+                if (ok_b) C[(long)row * p.ldc + col_b] = qb[r];
             }
         }
     } else if (EPI == EPI_UPDH) {
@@ -227,13 +236,20 @@ __device__ __forceinline__ void gemm_epilogue_pair(const GemmArgs& p, int file, 
             den[r] = E2[rc];
             sc[r] = E1 ? E1[rc] : 1.f;
         }
+        float ua[16], ub[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = den[r] + p.alpha + p.eps;
+            ua[r] = (ha[r] * sc[r]) * (acc_a[r] / d);
+            ub[r] = (hb[r] * sc[r]) * (acc_b[r] / d);
+            asm volatile("" : "+v"(ua[r]), "+v"(ub[r]));
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row_base + (r & 3) + 8 * (r >> 2);
-            const float d = den[r] + p.alpha + p.eps;
             if (row < p.M) {
-                if (ok_a) C[(long)row * p.ldc + col_a] = (ha[r] * sc[r]) * (acc_a[r] / d);
-                if (ok_b) C[(long)row * p.ldc + col_b] = (hb[r] * sc[r]) * (acc_b[r] / d);
+                if (ok_a) C[(long)row * p.ldc + col_a] = ua[r];
+                if (ok_b) C[(long)row * p.ldc + col_b] = ub[r];
             }
         }
     } else {  // EPI_PHASE: one tile at a time (X is two registers per element)
