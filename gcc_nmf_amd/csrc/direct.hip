@@ -963,8 +963,8 @@ __device__ __forceinline__ void gccnmf_whdiv_rht_item(const WhdivRhtArgs& p, con
         //     that block's operand for the next four frames; the divides of the next four frames ride in the first group.
         { const long long now = __builtin_amdgcn_s_memrealtime(); tt1 = c == 8 ? now : tt1; }      // tile 8: start (scalar registers; written out at the end)
         __builtin_amdgcn_s_setprio(2);                          // the first product is ONE dependent MFMA chain: it yields every other slot anyway
-        if (more) stage_load(h0, c + 1, 0);
-        const float vm = V[(long)p.M * p.ldv + min(64 * c + nl, p.ldv - 1)];
+        constexpr int REQ_CH = KB == 4 ? 1 : 0;                 // (always before the half-way store of the same rows)
+        float vm = 0.f;
         df32x4 v[4];
         f32x16 d;
 #pragma unroll
@@ -976,6 +976,14 @@ __device__ __forceinline__ void gccnmf_whdiv_rht_item(const WhdivRhtArgs& p, con
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
+            if (ch == REQ_CH) {
+                // the next tile's first staged rows and the tail bin's V are requested one chunk into the tile, not at its top, where the dictionary has 97 .. 128 atoms: this
+                // instantiation keeps nine values of the resident W operand in scratch, their reloads sit in the tile's first MFMA groups, and every scratch
+                // reload is followed by s_waitcnt vmcnt(0) -- with the requests at the top that wait was for the memory side, once per tile
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_load(h0, c + 1, 0);
+                vm = V[(long)p.M * p.ldv + min(64 * c + nl, p.ldv - 1)];
+            }
             if (ch == NCH / 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) {
